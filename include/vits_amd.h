@@ -1,0 +1,127 @@
+/* C ABI of libvits_amd.so: the MI355X (gfx950) implementation of the MVTS synthesis path.
+ *
+ * The reference (xirui123/VITS) is pure Python and has no FFI; the interface it exposes for this path is the
+ * Python method SynthesizerTrn.infer (reference models.py:717-767) on a module built by models.py:582-667 and
+ * filled by utils.load_checkpoint (utils.py:19-49).  Each entry point below names the reference code it replaces.
+ * The Python class vits_amd.SynthesizerTrn binds these with ctypes and reproduces the reference method's
+ * signature, return tuple and error behaviour.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless its name starts with host_; tensors are fp32,
+ * contiguous, channel-first [B, C, L]; phoneme ids and speaker ids are int64; lengths are int32.  All work is
+ * enqueued on `stream` (a hipStream_t passed as void*) and nothing synchronises unless stated.  Functions
+ * return 0 on success and a negative code on failure; vits_last_error() then holds a message (thread-local).
+ * No function allocates device memory: the caller passes a workspace sized by the matching *_workspace_bytes.
+ */
+#ifndef VITS_AMD_H
+#define VITS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITS_OK 0
+#define VITS_ERR_INVALID (-1)   /* bad argument / shape                      */
+#define VITS_ERR_MISSING (-2)   /* a tensor the model needs was never set    */
+#define VITS_ERR_HIP (-3)       /* a HIP call failed                         */
+#define VITS_ERR_WORKSPACE (-4) /* workspace too small                       */
+
+typedef struct vits_model vits_model;
+
+/* Hyper-parameters: the constructor arguments of SynthesizerTrn (reference models.py:582-606) plus the
+ * dimensions the reference hard-codes (models.py:540,642,644; frame_prior_network.py:65-67; attentions.py:11). */
+typedef struct vits_config {
+  int n_vocab, hidden_channels, inter_channels, filter_channels, n_heads, n_layers, kernel_size;
+  int gin_channels, n_speakers;
+  int pitch_layers, dur_filter, energy_filter;
+  int n_flows, flow_layers, flow_kernel, window_size;
+  int n_upsamples;
+  int upsample_rates[8], upsample_kernel_sizes[8], upsample_initial_channel;
+  int n_resblock_kernels, resblock_kernel_sizes[8], n_resblock_dilations, resblock_dilation_sizes[8][8];
+} vits_config;
+
+const char* vits_last_error(void);
+const char* vits_version(void);
+
+/* ---- model set-up (replaces module construction + utils.load_checkpoint, reference utils.py:19-49) ---- */
+int vits_model_create(const vits_config* cfg, vits_model** out);
+void vits_model_destroy(vits_model* m);
+/* Register a plain fp32 tensor (bias, LayerNorm gain, embedding table ...) under `name`. The memory stays owned
+ * by the caller and must outlive the model. */
+int vits_model_set_tensor(vits_model* m, const char* name, const float* dev_ptr, int64_t numel);
+/* Register a convolution whose weight was folded (weight-norm) and packed by vits_pack_conv_weight.
+ * mode: 0 plain, 1 gated (tanh*sigmoid halves), 2/3/4 transposed conv with stride 8/4/2.
+ * rows = packed GEMM rows (cout, or cout*stride for a transposed conv); bias has `rows` entries or is NULL. */
+int vits_model_set_conv(vits_model* m, const char* name, const float* packed_w, const float* bias_rows, int cin,
+                        int rows, int taps, int dilation, int mode);
+/* Resolve every name the synthesis path needs; fails with VITS_ERR_MISSING naming the first absent tensor. */
+int vits_model_finalize(vits_model* m);
+
+/* Host-side packing of one conv weight into MFMA fragment order.  host_w is the folded weight laid out as
+ * [rows][cin][taps] (row order for transposed convs: see vits_amd/weights.py); host_out gets rows*cin*taps floats. */
+int vits_pack_conv_weight(const float* host_w, int rows, int cin, int taps, float* host_out);
+
+/* ---- stages of SynthesizerTrn.infer ---- */
+
+/* Conditioning vectors from the speaker embedding: g = emb_g(sid) (reference models.py:719-720) pushed through
+ * every cond 1x1 conv (models.py:129,287,551; modules.py:149; frame_prior_network.py:126).  cond: [B, cond_rows]. */
+int vits_cond_rows(const vits_model* m);
+int vits_speaker_cond(const vits_model* m, const int64_t* sid, int B, float* cond, int* err_flag, void* stream);
+
+/* TextEncoder.forward (reference models.py:175-181): x [B, C, P]. */
+int64_t vits_encoder_workspace_bytes(const vits_model* m, int B, int L);
+int vits_text_encoder(const vits_model* m, const int64_t* phonemes, const int* lengths, int B, int P, float* x,
+                      int* err_flag, void* ws, int64_t ws_bytes, void* stream);
+
+/* attentions.Encoder.forward (reference attentions.py:32-44) in place on x [B, C, L]; which: 0 enc_p.encoder,
+ * 1 pitch_predictor.pitch_net, 2 frame_prior_net.fft_block. */
+int vits_encoder_stack(const vits_model* m, int which, float* x, const int* lengths, int B, int L, void* ws,
+                       int64_t ws_bytes, void* stream);
+
+/* Variance adaptor (reference models.py:726-753): duration / pitch / energy prediction or override and the two
+ * prenet updates of x (in place).  *_mode: 0 = predict and scale by *_scale, 1 = per-phoneme tensor override
+ * (pitch in Hz, energy in raw units; duration override is handled by the caller and skips the predictor).
+ * Outputs: dur_out [B, P] float (only when dur_mode == 0), f0_out, energy_out [B, P]. */
+int64_t vits_variance_workspace_bytes(const vits_model* m, int B, int P);
+int vits_variance_adaptor(const vits_model* m, float* x, const int* lengths, const float* cond, int B, int P,
+                          int dur_mode, float dur_scale, float* dur_out, int pitch_mode, float pitch_scale,
+                          const float* pitch_hz, float* f0_out, int energy_mode, float energy_scale,
+                          const float* energy_raw, float* energy_out, void* ws, int64_t ws_bytes, void* stream);
+
+/* LengthRegulator (reference models.py:418-460).  plan: integer durations -> inclusive prefix sums cum [B, P] and
+ * frame counts totals [B] (dur_dtype: 0 f32, 1 i64, 2 i32, 3 f64).  The caller reads totals to size x_frame, then
+ * gather writes x_frame [B, C, T] (zero beyond each row's frame count). */
+int vits_length_regulate_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, void* stream);
+int vits_length_regulate(const float* x, const int* cum, const int* totals, int B, int C, int P, int T, float* x_frame,
+                         void* stream);
+
+/* FramePriorNet + Projection + sampling (reference models.py:760-763): x_frame [B, C, T] is transformed in place;
+ * stats [B, 2C, T] receives (m_p, logs_p); z_p = m_p + noise * exp(logs_p) * noise_scale; z gets a copy of z_p. */
+int vits_frame_prior(const vits_model* m, float* x_frame, const int* frame_lengths, int B, int T, const float* noise,
+                     float noise_scale, float* stats, float* z_p, float* z, void* ws, int64_t ws_bytes, void* stream);
+
+/* ResidualCouplingBlock.forward(reverse=True) (reference models.py:209-216, modules.py:320-339) in place on z. */
+int64_t vits_flow_workspace_bytes(const vits_model* m, int B, int T);
+int vits_flow_reverse(const vits_model* m, float* z, const int* frame_lengths, const float* cond, int B, int T,
+                      void* ws, int64_t ws_bytes, void* stream);
+
+/* Generator.forward (reference models.py:284-303) on (z * mask)[:, :, :t_dec]: z has row stride T;
+ * wav [B, 1, t_dec * prod(upsample_rates)]. */
+int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec);
+int vits_generator(const vits_model* m, const float* z, const int* frame_lengths, const float* cond, int B, int T,
+                   int t_dec, float* wav, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- single operators, exposed for unit parity tests ---- */
+int vits_op_conv1d(const float* packed_w, const float* bias_rows, int cin, int rows, int taps, int dilation, int mode,
+                   const float* x, int B, int L, const int* lengths, const float* cbias, const float* in_cbias,
+                   const float* res, float* out, int flags, float in_scale, float in_slope, void* stream);
+int vits_op_layer_norm(const float* x, float* y, const float* gamma, const float* beta, const int* lengths, int B, int C,
+                       int L, int mask_out, void* stream);
+int vits_op_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out, int B,
+                      int H, int DK, int L, int window, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITS_AMD_H */

@@ -1,0 +1,102 @@
+"""End-to-end parity of vits_amd.SynthesizerTrn.infer on the GPU.
+
+Checked against (a) the golden vectors captured from the reference (tests/golden, tools/make_goldens.py) and
+(b) the CPU oracle on the same seeded inputs.  Tolerances (fp32 path): waveform max-abs <= 1e-4 and log-mel L1
+<= 1e-3, about 100x the fp32 noise floor measured between two CPU evaluations (1e-6 / 4e-7)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLDEN, SMALL_CASES, infer_kwargs, load_case
+from oracle import metrics
+from vits_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+WAV_TOL = 1e-4
+MEL_TOL = 1e-3
+LATENT_TOL = 2e-4      # z / z_p reach |20|; m_p, logs_p, stage tensors are O(1)
+
+
+@pytest.fixture(scope="module")
+def gpu_model(synthetic_sd):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from vits_amd import SynthesizerTrn
+    cfg = synthetic.ModelConfig()
+    net = SynthesizerTrn(cfg.n_vocab, cfg.spec_channels, cfg.hop_length, cfg.sampling_rate, cfg.segment_size,
+                         **cfg.kwargs()).eval()
+    net.load_state_dict(synthetic_sd)
+    return net
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_infer_matches_reference_goldens(gpu_model, name):
+    d, meta = load_case(name)
+    kw = infer_kwargs(d, meta)
+    st = {}
+    o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = gpu_model.infer(
+        d["in_phonemes"], d["in_lengths"], sid=d["in_sid"], noise=d["out_noise"], stages=st, **kw)
+    assert o.is_cuda and o.shape == d["out_o"].shape
+    assert x_mask.dtype == torch.bool and torch.equal(x_mask.cpu(), d["out_x_mask"])
+    assert torch.equal(st["x_lengths"].cpu(), d["stage_x_lengths"])
+    for got, key in ((st["enc_p"], "stage_enc_p"), (st["x_frame"], "stage_x_frame"), (st["prior"], "stage_prior"),
+                     (m_p, "out_m_p"), (logs_p, "out_logs_p"), (z_p, "out_z_p"), (z, "out_z")):
+        assert metrics.max_abs(got, d[key]) <= LATENT_TOL, key
+    assert metrics.max_abs(o, d["out_o"]) <= WAV_TOL
+    assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= MEL_TOL
+    assert (f0.cpu() - d["out_f0"]).abs().max() <= 1e-3 * max(1.0, float(d["out_f0"].abs().max()))
+    assert metrics.max_abs(energy, d["out_energy"]) <= 1e-3
+    dur = duration.cpu()
+    assert dur.shape == d["out_duration"].shape and dur.dtype == d["out_duration"].dtype
+    assert torch.equal(dur.to(torch.float64), d["out_duration"].to(torch.float64))
+
+
+def test_infer_c1_fullsize(gpu_model, oracle_model):
+    b = synthetic.config_c1()
+    g = np.load(os.path.join(GOLDEN, "c1.npz"))
+    kw = dict(noise_scale=b.noise_scale, duration_control=b.durations)
+    o = gpu_model.infer(b.phonemes, b.lengths, sid=b.sid, noise=b.noise, **kw)[0].cpu()
+    assert o.shape == (1, 1, 258 * 512)
+    assert np.abs(o[:, 0, ::97].numpy() - g["out_o_stride97"]).max() <= WAV_TOL          # reference samples
+    ref = oracle_model.infer(b.phonemes, b.lengths, sid=b.sid, noise=b.noise, **kw)[0]
+    assert metrics.max_abs(o, ref) <= WAV_TOL
+    assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= MEL_TOL
+
+
+def test_infer_c2_batch16_properties(gpu_model):
+    """Full-size batch (16 x 3 s): reference samples, and batch-composition independence for equal lengths
+    (no padding => each row equals its own batch-1 result)."""
+    b = synthetic.config_c2()
+    g = np.load(os.path.join(GOLDEN, "c2.npz"))
+    kw = dict(noise_scale=b.noise_scale, duration_control=b.durations)
+    o = gpu_model.infer(b.phonemes, b.lengths, sid=b.sid, noise=b.noise, **kw)[0]
+    assert o.shape == (16, 1, 258 * 512)
+    assert np.abs(o[:, 0, ::97].cpu().numpy() - g["out_o_stride97"]).max() <= WAV_TOL
+    lm = metrics.log_mel(o[:, 0].cpu())
+    assert np.abs(lm[:, ::8, ::8].numpy() - g["out_logmel_every8"]).max() <= 5e-2
+    i = 5
+    o1 = gpu_model.infer(b.phonemes[i:i + 1], b.lengths[i:i + 1], sid=b.sid[i:i + 1], noise=b.noise[i:i + 1],
+                         noise_scale=b.noise_scale, duration_control=b.durations[i:i + 1])[0]
+    assert metrics.max_abs(o1[0], o[i]) <= 1e-5
+    # determinism: same inputs, same bytes
+    o2 = gpu_model.infer(b.phonemes, b.lengths, sid=b.sid, noise=b.noise, **kw)[0]
+    assert torch.equal(o, o2)
+
+
+def test_infer_errors(gpu_model):
+    b = synthetic.make_batch(3, [6], [20])
+    with pytest.raises(TypeError):
+        gpu_model.infer(b.phonemes, b.lengths, duration_control=b.durations)
+    bad = b.phonemes.clone()
+    bad[0, 0] = 100000
+    with pytest.raises(IndexError):
+        gpu_model.infer(bad, b.lengths, sid=b.sid, duration_control=b.durations)
+    with pytest.raises(ValueError):
+        gpu_model.infer(b.phonemes, b.lengths, sid=b.sid, duration_control=torch.zeros_like(b.durations))
+    # random noise path runs and has the right shapes
+    o, x_mask, (z, z_p, m_p, logs_p), dur, f0, en = gpu_model.infer(b.phonemes, b.lengths, sid=b.sid, noise_scale=0.667,
+                                                                    duration_control=b.durations)
+    assert o.shape == (1, 1, 20 * 512) and torch.isfinite(o).all()
+    assert m_p.shape == logs_p.shape == z.shape == (1, 192, 20)

@@ -1,0 +1,199 @@
+"""Single-kernel parity on the GPU, through the C ABI (vits_op_*), against plain PyTorch fp32 on the CPU.
+
+Tolerances: fp32 MFMA accumulates in a different order than the CPU; with |values| ~ 1 and K <= 8448 products the
+difference stays below 2e-4 absolute (stated per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def N():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from vits_amd import _native
+    return _native
+
+
+def dev(t):
+    return None if t is None else t.cuda().contiguous()
+
+
+def gpu_conv(N, w, bias, x, dilation=1, mode=0, flags=0, lengths=None, cbias=None, in_cbias=None, res=None,
+             out_init=None, in_scale=1.0, in_slope=1.0, up=1, bias_rows=None):
+    """w: logical [rows, cin, taps] (already in kernel row order for transposed convs)."""
+    from vits_amd import weights
+    rows, cin, taps = w.shape
+    B, _, L = x.shape
+    cout = rows // 2 if mode == N.MODE_GATE else rows // up
+    pk = dev(weights.pack_rows(w))
+    b = dev(bias_rows if bias_rows is not None else bias)
+    xd, ld, cb, icb, rd = dev(x), dev(lengths), dev(cbias), dev(in_cbias), dev(res)
+    out = dev(out_init) if out_init is not None else torch.full((B, cout, L * up), float("nan"), device="cuda")
+    N.check(N.lib.vits_op_conv1d(pk.data_ptr(), N.ptr(b), cin, rows, taps, dilation, mode, xd.data_ptr(), B, L,
+                                 N.ptr(ld), N.ptr(cb), N.ptr(icb), N.ptr(rd), out.data_ptr(), flags, in_scale,
+                                 in_slope, torch.cuda.current_stream().cuda_stream), "op_conv1d")
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+CONV_CASES = [
+    # cout, cin, k, dil, B, L
+    (64, 32, 3, 1, 2, 300),       # <2,2,1,4>
+    (256, 256, 11, 5, 1, 700),    # widest receptive field (halo 50)
+    (32, 32, 7, 3, 2, 1500),      # <1,4,1,4>
+    (32, 64, 3, 1, 1, 250),       # <1,2,1,4>
+    (96, 192, 1, 1, 2, 70),       # <1,1,1,4>
+    (768, 192, 3, 1, 2, 50),      # <2,1,2,2> short sequence
+    (192, 768, 3, 1, 3, 37),
+    (576, 192, 1, 1, 2, 258),
+    (512, 192, 7, 1, 1, 258),
+    (64, 16, 5, 1, 1, 1),         # single time step
+]
+
+
+@pytest.mark.parametrize("cout,cin,k,dil,B,L", CONV_CASES)
+def test_conv_plain(N, cout, cin, k, dil, B, L):
+    g = torch.Generator().manual_seed(cout * 131 + cin + k + L)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    x = torch.randn(B, cin, L, generator=g)
+    ref = F.conv1d(x, w, b, padding=(k - 1) // 2 * dil, dilation=dil)
+    got = gpu_conv(N, w, b, x, dilation=dil)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() < 2e-5
+
+
+def test_conv_prologue_epilogue_flags(N):
+    g = torch.Generator().manual_seed(7)
+    cout, cin, k, B, L = 64, 48, 3, 3, 333
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    x = torch.randn(B, cin, L, generator=g)
+    lengths = torch.tensor([333, 200, 17], dtype=torch.int32)
+    m = (torch.arange(L)[None, :] < lengths[:, None]).float()[:, None, :]
+    cbias = torch.randn(B, cout, generator=g)
+    icb = torch.randn(B, cin, generator=g)
+    res = torch.randn(B, cout, L, generator=g)
+    init = torch.randn(B, cout, L, generator=g)
+    # input: ((x + in_cbias) * scale) -> lrelu -> mask ; output: relu -> mask -> + res -> + out -> mask
+    xin = F.leaky_relu((x + icb[:, :, None]) * 0.5, 0.1) * m
+    y = F.conv1d(xin, w, b, padding=1) + cbias[:, :, None]
+    ref = ((torch.relu(y) * m) + res + init) * m
+    flags = N.F_IN_LRELU | N.F_IN_MASK | N.F_RELU | N.F_MASK_PRE | N.F_RES | N.F_ACCUM | N.F_MASK_POST
+    got = gpu_conv(N, w, b, x, flags=flags, lengths=lengths, cbias=cbias, in_cbias=icb, res=res, out_init=init,
+                   in_scale=0.5, in_slope=0.1)
+    assert (got - ref).abs().max() < 2e-5
+    # res - y form used by the coupling layer
+    ref2 = (res - (F.conv1d(x, w, b, padding=1) * m)) * m
+    got2 = gpu_conv(N, w, b, x, flags=N.F_MASK_PRE | N.F_RES_SUB | N.F_MASK_POST, lengths=lengths, res=res)
+    assert (got2 - ref2).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("L", [40, 258, 700])
+def test_conv_gate(N, L):
+    g = torch.Generator().manual_seed(L)
+    H, k, B = 192, 5, 2
+    w = torch.randn(2 * H, H, k, generator=g) / math.sqrt(H * k)
+    b = torch.randn(2 * H, generator=g)
+    x = torch.randn(B, H, L, generator=g)
+    cb = torch.randn(B, 2 * H, generator=g)
+    a = F.conv1d(x, w, b, padding=2) + cb[:, :, None]
+    ref = torch.tanh(a[:, :H]) * torch.sigmoid(a[:, H:])
+    got = gpu_conv(N, w, b, x, mode=N.MODE_GATE, cbias=cb)
+    assert (got - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("u,k,cin,cout,L", [(8, 16, 512, 256, 258), (8, 16, 256, 128, 1500), (4, 4, 128, 64, 700),
+                                            (2, 4, 64, 32, 1111), (8, 16, 32, 16, 3)])
+def test_conv_transpose(N, u, k, cin, cout, L):
+    from vits_amd import weights
+    g = torch.Generator().manual_seed(u * 1000 + L)
+    wt = torch.randn(cin, cout, k, generator=g) / math.sqrt(cin * k / u)
+    b = torch.randn(cout, generator=g)
+    x = torch.randn(2, cin, L, generator=g)
+    if cout * u % 64:
+        pytest.skip("rows must be a multiple of 64")
+    ref = F.conv_transpose1d(F.leaky_relu(x / 3, 0.1), wt, b, stride=u, padding=(k - u) // 2)
+    w_rows, b_rows, mode, taps = weights.transposed_conv_rows(wt, b, u, k, (k - u) // 2)
+    got = gpu_conv(N, w_rows, None, x, mode=mode, up=u, bias_rows=b_rows, flags=N.F_IN_LRELU, in_scale=1.0 / 3,
+                   in_slope=0.1)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("C,L,mask", [(192, 50, False), (256, 333, True), (768, 70, False), (192, 1, True)])
+def test_layer_norm(N, C, L, mask):
+    g = torch.Generator().manual_seed(C + L)
+    B = 3
+    x = torch.randn(B, C, L, generator=g) * 3 + 1
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    lengths = torch.tensor([L, max(L // 2, 1), 1], dtype=torch.int32)
+    ref = F.layer_norm(x.transpose(1, 2), (C,), gamma, beta, 1e-5).transpose(1, 2)
+    if mask:
+        ref = ref * (torch.arange(L)[None, :] < lengths[:, None]).float()[:, None, :]
+    xd, y = dev(x), torch.empty(B, C, L, device="cuda")
+    gd, bd, ld = dev(gamma), dev(beta), dev(lengths)
+    N.check(N.lib.vits_op_layer_norm(xd.data_ptr(), y.data_ptr(), gd.data_ptr(), bd.data_ptr(),
+                                     ld.data_ptr(), B, C, L, int(mask), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert (y.cpu() - ref).abs().max() < 1e-5
+    # in place
+    N.check(N.lib.vits_op_layer_norm(xd.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(),
+                                     ld.data_ptr(), B, C, L, int(mask), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert (xd.cpu() - ref).abs().max() < 1e-5
+
+
+def reference_attention(q, k, v, ek, ev, lengths, H, W=4):
+    """The reference's formulation with padded relative embeddings and skew reshapes (attentions.py:226-321),
+    restated independently of the oracle's banded version."""
+    B, C, L = q.shape
+    dk = C // H
+    q = q.view(B, H, dk, L).transpose(2, 3)
+    k = k.view(B, H, dk, L).transpose(2, 3)
+    v = v.view(B, H, dk, L).transpose(2, 3)
+
+    def rel_emb(e):
+        pad = max(L - (W + 1), 0)
+        start = max((W + 1) - L, 0)
+        e = F.pad(e, (0, 0, pad, pad))
+        return e[start:start + 2 * L - 1]
+
+    def rel_to_abs(x):
+        x = F.pad(x, (0, 1)).reshape(B, H, L * 2 * L)
+        x = F.pad(x, (0, L - 1))
+        return x.view(B, H, L + 1, 2 * L - 1)[:, :, :L, L - 1:]
+
+    def abs_to_rel(x):
+        x = F.pad(x, (0, L - 1)).reshape(B, H, L * L + L * (L - 1))
+        x = F.pad(x, (L, 0))
+        return x.view(B, H, L, 2 * L)[:, :, :, 1:]
+    qs = q / math.sqrt(dk)
+    scores = qs @ k.transpose(-2, -1) + rel_to_abs(qs @ rel_emb(ek).t())
+    m = torch.arange(L)[None, :] < lengths[:, None]
+    mask = (m[:, None, :] & m[:, :, None])[:, None]
+    scores = scores.masked_fill(~mask, -1e4)
+    p = F.softmax(scores, dim=-1)
+    out = p @ v + abs_to_rel(p) @ rel_emb(ev)
+    return out.transpose(2, 3).reshape(B, C, L)
+
+
+@pytest.mark.parametrize("L", [3, 12, 50, 130, 258, 600])
+def test_attention(N, L):
+    g = torch.Generator().manual_seed(L)
+    B, H, dk = 2, 2, 96
+    C = H * dk
+    qkv = torch.randn(B, 3 * C, L, generator=g)
+    ek, ev = torch.randn(9, dk, generator=g) * 0.1, torch.randn(9, dk, generator=g) * 0.1
+    lengths = torch.tensor([L, max(1, (2 * L) // 3)], dtype=torch.int32)
+    ref = reference_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ek, ev, lengths, H)
+    out = torch.empty(B, C, L, device="cuda")
+    qd, kd, vd, ld = dev(qkv), dev(ek), dev(ev), dev(lengths)
+    N.check(N.lib.vits_op_attention(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ld.data_ptr(),
+                                    out.data_ptr(), B, H, dk, L, 4, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 2e-5

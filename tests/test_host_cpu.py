@@ -1,0 +1,103 @@
+"""CPU-side checks: the shared library loads and exports the whole C ABI, weight packing / polyphase row order is
+right (emulated in numpy against torch's conv ops), and the config / checkpoint helpers behave like the
+reference's (reference utils.py:19-49, 217-223, 280-309)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vits_amd import _native as N
+from vits_amd import synthetic, utils, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "vits_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(vits_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(N.lib, name), f"{name} declared in include/vits_amd.h but not exported"
+    assert declared == set(N.EXPORTED)
+    assert b"gfx950" in N.lib.vits_version()
+
+
+def unpack(packed, rows, cin, taps):
+    """Inverse of the fragment order documented in csrc/common.h: [cin/16][taps][2][rows/32][64 lanes][4]."""
+    p = packed.numpy().reshape(cin // 16, taps, 2, rows // 32, 64, 4)
+    w = np.zeros((rows, cin, taps), dtype=np.float32)
+    for lane in range(64):
+        for e in range(4):
+            r, par = lane & 31, lane >> 5
+            # row = mt*32 + r ; ci = chunk*16 + sq*8 + e*2 + par
+            blk = p[:, :, :, :, lane, e]                     # [chunk, tap, sq, mt]
+            for sq in range(2):
+                ci = np.arange(cin // 16) * 16 + sq * 8 + e * 2 + par
+                w[r::32, :, :][:, ci, :] = np.transpose(blk[:, :, sq, :], (2, 0, 1))
+    return w
+
+
+def test_pack_roundtrip():
+    torch.manual_seed(0)
+    w = torch.randn(64, 32, 5)
+    assert np.array_equal(unpack(weights.pack_rows(w), 64, 32, 5), w.numpy())
+
+
+def emulate_transposed(w_rows, bias_rows, mode, x, up):
+    """What the conv kernel computes for a transposed conv: GEMM rows with per-class tap offsets, then the
+    row -> (channel, phase) scatter of its epilogue."""
+    rows, cin, taps = w_rows.shape
+    cout, L = rows // up, x.shape[-1]
+    xp = F.pad(x, (2, 2)).numpy()
+    out = np.zeros((x.shape[0], cout, L * up), dtype=np.float64)
+    for row in range(rows):
+        mt, rit = divmod(row, 32)
+        g, h, jj = rit // 8, (rit // 4) % 2, rit % 4
+        if mode == N.MODE_UP8:
+            cb, cls = divmod(mt, 2); co, r = cb * 8 + 2 * g + h, 4 * cls + jj
+        elif mode == N.MODE_UP4:
+            cls = 0; co, r = mt * 8 + 2 * g + h, jj
+        else:
+            cb, cls = divmod(mt, 2); co, r = cb * 32 + rit, cls
+        acc = np.zeros((x.shape[0], L))
+        for j in range(taps):
+            off = (cls - j) if mode != N.MODE_UP4 else 0       # toff0 = class, tstep = -1
+            acc += np.einsum("c,bct->bt", w_rows[row, :, j].numpy().astype(np.float64), xp[:, :, 2 + off:2 + off + L])
+        out[:, co, r::up] = acc + float(bias_rows[row])
+    return out
+
+
+@pytest.mark.parametrize("u,k,cin,cout", [(8, 16, 16, 16), (4, 4, 16, 16), (2, 4, 16, 32)])
+def test_polyphase_rows_match_conv_transpose1d(u, k, cin, cout):
+    torch.manual_seed(1)
+    wt, b, x = torch.randn(cin, cout, k), torch.randn(cout), torch.randn(2, cin, 9)
+    w_rows, b_rows, mode, taps = weights.transposed_conv_rows(wt, b, u, k, (k - u) // 2)
+    ref = F.conv_transpose1d(x.double(), wt.double(), b.double(), stride=u, padding=(k - u) // 2).numpy()
+    got = emulate_transposed(w_rows, b_rows, mode, x, u)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 1e-5
+
+
+def test_prepare_covers_every_used_key(synthetic_sd):
+    cfg = synthetic.ModelConfig()
+    pw = weights.prepare(synthetic_sd, cfg)
+    assert len(pw.convs) == 14 * 4 + 2 + 2 + 1 + 4 * (2 + 4 + 3 + 4) + 1 + 4 + 72
+    flow0 = pw.convs["flow.0.in.0"]
+    assert flow0[2:] == (192, 384, 5, 1, N.MODE_GATE)
+    assert pw.plain["cond.w"].numel() == (3 * 192 + 512 + 4 * 1536) * 256
+
+
+def test_hparams_and_config_reader(tmp_path):
+    text = '{\n "train": {"seed": 1234}, // trailing comment\n /* block\n comment */ "model": {"n_heads": 2, "url": "http://x/y"}\n}'
+    p = tmp_path / "config.json"
+    p.write_bytes(text.encode("gbk"))
+    hps = utils.get_hparams_from_file(str(p))
+    assert hps.train.seed == 1234 and hps.model["n_heads"] == 2 and "model" in hps and len(hps) == 2
+    assert hps.model.url == "http://x/y"
+    p.write_text(json.dumps({"a": {"b": 1}}))
+    assert utils.get_hparams_from_file(str(p)).a.b == 1

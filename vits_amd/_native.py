@@ -1,0 +1,87 @@
+"""ctypes binding of libvits_amd.so (C ABI in include/vits_amd.h).
+
+There is no fallback: if the shared library is missing or fails to load, importing this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvits_amd.so")
+
+
+class VitsConfig(C.Structure):
+    _fields_ = [
+        ("n_vocab", C.c_int), ("hidden_channels", C.c_int), ("inter_channels", C.c_int),
+        ("filter_channels", C.c_int), ("n_heads", C.c_int), ("n_layers", C.c_int), ("kernel_size", C.c_int),
+        ("gin_channels", C.c_int), ("n_speakers", C.c_int),
+        ("pitch_layers", C.c_int), ("dur_filter", C.c_int), ("energy_filter", C.c_int),
+        ("n_flows", C.c_int), ("flow_layers", C.c_int), ("flow_kernel", C.c_int), ("window_size", C.c_int),
+        ("n_upsamples", C.c_int),
+        ("upsample_rates", C.c_int * 8), ("upsample_kernel_sizes", C.c_int * 8),
+        ("upsample_initial_channel", C.c_int),
+        ("n_resblock_kernels", C.c_int), ("resblock_kernel_sizes", C.c_int * 8),
+        ("n_resblock_dilations", C.c_int), ("resblock_dilation_sizes", (C.c_int * 8) * 8),
+    ]
+
+
+class VitsError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m vits_amd.build` (hipcc, gfx950). "
+            "vits_amd has no CPU or PyTorch fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    sig = {
+        "vits_last_error": (C.c_char_p, []),
+        "vits_version": (C.c_char_p, []),
+        "vits_model_create": (i32, [C.POINTER(VitsConfig), C.POINTER(vp)]),
+        "vits_model_destroy": (None, [vp]),
+        "vits_model_set_tensor": (i32, [vp, C.c_char_p, vp, i64]),
+        "vits_model_set_conv": (i32, [vp, C.c_char_p, vp, vp, i32, i32, i32, i32, i32]),
+        "vits_model_finalize": (i32, [vp]),
+        "vits_pack_conv_weight": (i32, [vp, i32, i32, i32, vp]),
+        "vits_cond_rows": (i32, [vp]),
+        "vits_speaker_cond": (i32, [vp, vp, i32, vp, vp, vp]),
+        "vits_encoder_workspace_bytes": (i64, [vp, i32, i32]),
+        "vits_text_encoder": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, i64, vp]),
+        "vits_encoder_stack": (i32, [vp, i32, vp, vp, i32, i32, vp, i64, vp]),
+        "vits_variance_workspace_bytes": (i64, [vp, i32, i32]),
+        "vits_variance_adaptor": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, i32, f32, vp, vp, i32, f32, vp, vp,
+                                        vp, i64, vp]),
+        "vits_length_regulate_plan": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+        "vits_length_regulate": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+        "vits_frame_prior": (i32, [vp, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp, i64, vp]),
+        "vits_flow_workspace_bytes": (i64, [vp, i32, i32]),
+        "vits_flow_reverse": (i32, [vp, vp, vp, vp, i32, i32, vp, i64, vp]),
+        "vits_generator_workspace_bytes": (i64, [vp, i32, i32]),
+        "vits_generator": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp]),
+        "vits_op_conv1d": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, f32, f32, vp]),
+        "vits_op_layer_norm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+        "vits_op_attention": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)      # AttributeError here means the library does not match include/vits_amd.h
+        fn.restype = res
+        fn.argtypes = args
+    return lib, list(sig.keys())
+
+
+lib, EXPORTED = _load()
+
+MODE_PLAIN, MODE_GATE, MODE_UP8, MODE_UP4, MODE_UP2 = 0, 1, 2, 3, 4
+F_IN_LRELU, F_IN_MASK, F_RELU, F_MASK_PRE, F_RES, F_RES_SUB, F_ACCUM, F_MASK_POST = (1 << i for i in range(8))
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise VitsError(f"{what or 'vits_amd'} failed ({rc}): {lib.vits_last_error().decode()}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a torch tensor / None."""
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,95 @@
+// Shared declarations for the MVTS synthesis kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vits {
+
+// ---------------------------------------------------------------------------------------------------------
+// conv1d / conv_transpose1d as an fp32 MFMA implicit GEMM:  out[row, t] = sum_{ci, tap} W[row, ci, tap] * x[ci, t + toff(tap)]
+// ---------------------------------------------------------------------------------------------------------
+enum ConvMode : int {
+  MODE_PLAIN = 0,   // rows are output channels
+  MODE_GATE  = 1,   // rows [0, M/2) and [M/2, M) are combined as tanh(a) * sigmoid(s)  (WaveNet gate)
+  MODE_UP8   = 2,   // transposed conv, stride 8, kernel 16, padding 4: rows are (channel, phase) pairs
+  MODE_UP4   = 3,   // transposed conv, stride 4, kernel 4,  padding 0
+  MODE_UP2   = 4,   // transposed conv, stride 2, kernel 4,  padding 1
+};
+
+enum ConvFlags : int {
+  F_IN_LRELU  = 1 << 0,   // leaky-relu(in_slope) on the input
+  F_IN_MASK   = 1 << 1,   // input *= (t < len[b])
+  F_RELU      = 1 << 2,   // relu on the result
+  F_MASK_PRE  = 1 << 3,   // result *= mask before residual / accumulate
+  F_RES       = 1 << 4,   // result += res
+  F_RES_SUB   = 1 << 5,   // result = res - result
+  F_ACCUM     = 1 << 6,   // result += out (read-modify-write)
+  F_MASK_POST = 1 << 7,   // result *= mask last
+};
+
+constexpr int CI_CHUNK = 16;    // input channels staged per LDS tile
+constexpr int MAX_TAPS = 12;
+constexpr int MAX_HALO = 64;    // max (max_off - min_off) a tile may need
+
+struct ConvDesc {          // one packed convolution, immutable after load
+  const float* w = nullptr;      // packed [Cin/16][K][2][M/32][64][4]
+  const float* bias = nullptr;   // [M] per-row bias, may be null
+  int Cin = 0, M = 0, K = 0, mode = MODE_PLAIN;
+  int toff0[2] = {0, 0};         // input time offset of tap k, per row class: toff0 + k * tstep
+  int tstep[2] = {0, 0};
+  int min_off = 0, max_off = 0;
+  int up = 1;                    // output time stride (1, 2, 4, 8)
+  int cout = 0;                  // logical output channels
+};
+
+struct ConvArgs {
+  const float* x; long long x_bs; int x_cs;          // input [B][Cin][*], batch / channel strides in floats
+  const float* w; const float* bias;
+  const float* cbias; int cbias_bs;                  // per-(batch,row) additive bias, or null
+  const float* in_cbias; int in_cbias_bs;            // per-(batch,ci) additive input bias, or null
+  float* out; long long out_bs; int out_cs;
+  const float* res; long long res_bs; int res_cs;
+  const int* lengths;                                // per-batch valid length, or null (all valid)
+  int B, Cin, M, K, L;                               // L = number of time positions (input length)
+  int mt_total;                                      // M / 32
+  int min_off, width;                                // LDS tile covers t0 + min_off .. + width
+  int rs;                                            // LDS row stride in floats
+  int flags;
+  float in_scale, in_slope;
+  int toff0[2], tstep[2];                            // tap k reads x[t + toff0 + k * tstep] (per row class)
+};
+
+hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------
+// other kernels (kernels_misc.hip)
+// ---------------------------------------------------------------------------------------------------------
+hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta, const int* lengths,
+                             int B, int C, int L, bool mask_out, hipStream_t s);
+hipError_t launch_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
+                            int B, int H, int DK, int L, int window, hipStream_t s);
+hipError_t launch_embed(const int64_t* ids, const float* table, const int* lengths, float* x, int B, int P, int C,
+                        int n_vocab, int* err_flag, hipStream_t s);
+hipError_t launch_cond_gemv(const float* emb_g, const int64_t* sid, const float* w, const float* bias, float* out,
+                            int B, int rows, int gin, int n_speakers, int* err_flag, hipStream_t s);
+hipError_t launch_add_cbias_mask(const float* x, const float* cb, int cb_bs, const int* lengths, float* y, int B, int C,
+                                 int L, bool mask, hipStream_t s);
+// out[b][t] = act(bias + sum_{c,k} w[c*K+k] * pro(x[b][c][t + k - pad]))
+hipError_t launch_conv_to1(const float* x, long long x_bs, int x_cs, const float* w, const float* bias, float* out,
+                           const int* lengths, int B, int C, int K, int L, int flags, float in_scale, float in_slope,
+                           bool tanh_out, bool mask_out, hipStream_t s);
+hipError_t launch_prenet_add(float* x, const float* sig, const float* w, const float* bias, int B, int C, int L,
+                             hipStream_t s);
+hipError_t launch_duration_finalize(const float* logw, const int* lengths, float scale, float* dur, int B, int P,
+                                    hipStream_t s);
+hipError_t launch_pitch_math(const float* in, bool in_is_hz, float scale, float* lf0, float* f0, int n, hipStream_t s);
+hipError_t launch_energy_math(const float* in, bool in_is_raw, float scale, float* norm, float* energy, int n,
+                              hipStream_t s);
+hipError_t launch_sample(const float* stats, const float* noise, float noise_scale, float* z_p, float* z, int B, int C,
+                         int L, hipStream_t s);
+// length regulator
+hipError_t launch_lr_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, hipStream_t s);
+hipError_t launch_lr_gather(const float* x, const int* cum, const int* totals, float* out, int B, int C, int P, int T,
+                            hipStream_t s);
+
+}  // namespace vits

@@ -1,0 +1,317 @@
+// fp32 MFMA implicit-GEMM convolution for gfx950 (v_mfma_f32_32x32x2_f32, wave64).
+//
+// One kernel serves every conv1d / conv_transpose1d on the synthesis path (reference: nn.Conv1d uses in
+// attentions.py:196-199,373-374, models.py:116-120,263-283,543,567,657-658, modules.py:129-142,187-202,314-316,
+// frame_prior_network.py:39-47).
+//
+//   GEMM view:  D[row, t] = sum over (ci, tap) of  W[row, ci, tap] * X[ci, t + toff(tap)]
+//     M = rows (output channels; for a transposed conv: (channel, phase) pairs), N = time, K = Cin * taps.
+//   A operand (weights) comes pre-packed in exact fragment order, so each lane fetches one float4 per four
+//   k-steps straight from global memory (L2-resident, 1 KiB per wave instruction, no LDS round trip).
+//   B operand (activations) is staged per 16 input channels into an LDS tile [16][BN + halo] with the input
+//   prologue (scale, leaky-relu, conditioning bias, length mask, zero padding) applied once at staging; MFMA
+//   B fragments are conflict-free ds_read_b32 (lanes = consecutive time steps).
+//   The next channel chunk is prefetched into registers while the current chunk is multiplied.
+//   C/D: column = time = lane & 31, so every accumulator register stores 128 contiguous bytes per half wave.
+#include "common.h"
+
+namespace vits {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int WM, int WN, int WGM, int WGN, int MODE>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int BN = 32 * WN * WGN;
+  constexpr int NCOLS = (BN + MAX_HALO + 63) / 64;
+  constexpr bool TWO_CLASS = (MODE == MODE_UP8 || MODE == MODE_UP2);
+  constexpr int NB = TWO_CLASS ? 2 : 1;
+  static_assert(WGM * WGN == 4, "four waves per block");
+  static_assert(!TWO_CLASS || WM == 2, "two-class transposed convs pair the classes in one wave");
+  static_assert(MODE != MODE_GATE || WM == 2, "gate pairs the tanh and sigmoid rows in one wave");
+
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int par = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BN;
+  const int len_b = a.lengths ? a.lengths[b] : 0x7fffffff;
+  const int rs = a.rs;
+
+  int mt[WM];
+  bool mt_ok[WM];
+  if constexpr (MODE == MODE_GATE) {
+    const int half = a.mt_total >> 1;
+    const int p = blockIdx.y * WGM + wm;
+    mt_ok[0] = mt_ok[WM - 1] = p < half;
+    mt[0] = p < half ? p : half - 1;
+    mt[WM - 1] = mt[0] + half;
+  } else {
+    const int base = (blockIdx.y * WGM + wm) * WM;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      mt_ok[i] = base + i < a.mt_total;
+      mt[i] = mt_ok[i] ? base + i : a.mt_total - 1;
+    }
+  }
+
+  // ---- activation staging (global -> registers -> LDS) ----
+  const float* xb = a.x + (long long)b * a.x_bs;
+  const int tstart = t0 + a.min_off;
+  float st[4][NCOLS];
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* xr = xb + (long long)(chunk * CI_CHUNK + wave * 4 + r) * a.x_cs;
+#pragma unroll
+      for (int q = 0; q < NCOLS; ++q) {
+        const int col = lane + 64 * q, t = tstart + col;
+        const bool ok = col < a.width && t >= 0 && t < a.L;
+        st[r][q] = ok ? xr[t] : 0.f;
+      }
+    }
+  };
+  auto store_chunk = [&](int chunk) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 4 + r;
+      const float cb = a.in_cbias ? a.in_cbias[(long long)b * a.in_cbias_bs + chunk * CI_CHUNK + row] : 0.f;
+#pragma unroll
+      for (int q = 0; q < NCOLS; ++q) {
+        const int col = lane + 64 * q, t = tstart + col;
+        float v = (st[r][q] + cb) * a.in_scale;
+        if (a.flags & F_IN_LRELU) v = v > 0.f ? v : v * a.in_slope;
+        bool ok = t >= 0 && t < a.L;
+        if (a.flags & F_IN_MASK) ok = ok && t < len_b;
+        if (col < a.width) xs[row * rs + col] = ok ? v : 0.f;
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- weight fragment stream: one float4 per (m-tile, iteration), iteration = (chunk, tap, 8-channel half) ----
+  // Two fragment register sets ping-pong (A0 for the even half, A1 for the odd half of each tap), so each load has
+  // a full 4*WM*WN-MFMA half-iteration to land and no register copies sit between MFMAs.
+  const long long it_stride = (long long)a.mt_total * 64;   // in float4
+  const float4* wp[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) wp[i] = reinterpret_cast<const float4*>(a.w) + (long long)mt[i] * 64 + lane;
+  const int nchunks = a.Cin / CI_CHUNK;
+  const int n_it = nchunks * a.K * 2;
+  float4 A0[WM], A1[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) A0[i] = wp[i][0];
+  int it = 0;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  auto half_step = [&](const float4 (&af)[WM], const int (&boff)[NB], int sq) {
+    float bv[4][NB][WN];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < NB; ++c)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bv[e][c][j] = xs[(sq * 8 + e * 2) * rs + boff[c] + j * 32];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const float av = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e][TWO_CLASS ? i : 0][j], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  const int colbase = wn * WN * 32 + l31 + par * rs - a.min_off;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+    int boff[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) boff[c] = colbase + a.toff0[c];
+    for (int k = 0; k < a.K; ++k) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) A1[i] = wp[i][(long long)(it + 1) * it_stride];
+      __builtin_amdgcn_sched_barrier(0);   // keep the fragment prefetch ahead of the MFMA half-step
+      half_step(A0, boff, 0);
+      it += 2;
+      if (it < n_it) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) A0[i] = wp[i][(long long)it * it_stride];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      half_step(A1, boff, 1);
+#pragma unroll
+      for (int c = 0; c < NB; ++c) boff[c] += a.tstep[c];
+    }
+    if (chunk + 1 < nchunks) {
+      __syncthreads();
+      store_chunk(chunk + 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue ----
+  const float* cbias_b = a.cbias ? a.cbias + (long long)b * a.cbias_bs : nullptr;
+  float* out_b = a.out + (long long)b * a.out_bs;
+  if constexpr (MODE == MODE_PLAIN) {
+    const float* res_b = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      if (!mt_ok[i]) continue;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + (wn * WN + j) * 32 + l31;
+        if (t >= a.L) continue;
+        const float m = t < len_b ? 1.f : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * par;
+          float v = acc[i][j][r];
+          if (a.bias) v += a.bias[row];
+          if (cbias_b) v += cbias_b[row];
+          if (a.flags & F_RELU) v = fmaxf(v, 0.f);
+          if (a.flags & F_MASK_PRE) v *= m;
+          if (a.flags & (F_RES | F_RES_SUB)) {
+            const float rv = res_b[(long long)row * a.res_cs + t];
+            v = (a.flags & F_RES_SUB) ? rv - v : v + rv;
+          }
+          float* op = out_b + (long long)row * a.out_cs + t;
+          if (a.flags & F_ACCUM) v += *op;
+          if (a.flags & F_MASK_POST) v *= m;
+          *op = v;
+        }
+      }
+    }
+  } else if constexpr (MODE == MODE_GATE) {
+    if (mt_ok[0]) {
+      const int hrows = a.M >> 1;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + (wn * WN + j) * 32 + l31;
+        if (t >= a.L) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt[0] * 32 + (r & 3) + 8 * (r >> 2) + 4 * par;
+          float va = acc[0][j][r], vs = acc[WM - 1][j][r];
+          if (a.bias) { va += a.bias[row]; vs += a.bias[row + hrows]; }
+          if (cbias_b) { va += cbias_b[row]; vs += cbias_b[row + hrows]; }
+          out_b[(long long)row * a.out_cs + t] = tanhf(va) * (1.f / (1.f + expf(-vs)));
+        }
+      }
+    }
+  } else if constexpr (MODE == MODE_UP8 || MODE == MODE_UP4) {
+    // rows of an m-tile: 8*g + 4*par + jj  ->  channel = cb*8 + 2*g + par, phase = jj (+4 for the second class)
+    constexpr int UP = MODE == MODE_UP8 ? 8 : 4;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      if (!mt_ok[i]) continue;
+      const int cb = MODE == MODE_UP8 ? (mt[i] >> 1) : mt[i];
+      const int ph0 = MODE == MODE_UP8 ? 4 * (mt[i] & 1) : 0;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + (wn * WN + j) * 32 + l31;
+        if (t >= a.L) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = cb * 8 + 2 * g + par;
+          const float bz = a.bias ? a.bias[mt[i] * 32 + 8 * g + 4 * par] : 0.f;
+          float4 v;
+          v.x = acc[i][j][4 * g + 0] + bz;
+          v.y = acc[i][j][4 * g + 1] + bz;
+          v.z = acc[i][j][4 * g + 2] + bz;
+          v.w = acc[i][j][4 * g + 3] + bz;
+          *reinterpret_cast<float4*>(out_b + (long long)co * a.out_cs + (long long)UP * t + ph0) = v;
+        }
+      }
+    }
+  } else {  // MODE_UP2: m-tile = 32 channels of one phase
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      if (!mt_ok[i]) continue;
+      const int cb = mt[i] >> 1, ph = mt[i] & 1;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + (wn * WN + j) * 32 + l31;
+        if (t >= a.L) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = (r & 3) + 8 * (r >> 2) + 4 * par;
+          float v = acc[i][j][r];
+          if (a.bias) v += a.bias[mt[i] * 32 + rl];
+          out_b[(long long)(cb * 32 + rl) * a.out_cs + 2LL * t + ph] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int WGM, int WGN, int MODE>
+static hipError_t launch_cfg(ConvArgs& a, hipStream_t stream) {
+  constexpr int BN = 32 * WN * WGN;
+  a.width = BN + (a.width);          // caller passes halo span in a.width
+  a.rs = (a.width + 3) & ~3;
+  const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + WM - 1) / WM;
+  dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
+  const size_t lds = (size_t)CI_CHUNK * a.rs * sizeof(float);
+  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
+  if (d.Cin % CI_CHUNK != 0 || d.M % 32 != 0 || d.K < 1 || d.K > MAX_TAPS) return hipErrorInvalidValue;
+  if (d.max_off - d.min_off > MAX_HALO) return hipErrorInvalidValue;
+  if (a.B <= 0 || a.L <= 0) return hipErrorInvalidValue;
+  if (a.B > 65535) return hipErrorInvalidValue;
+  a.w = d.w;
+  a.bias = d.bias;
+  a.Cin = d.Cin;
+  a.M = d.M;
+  a.K = d.K;
+  a.mt_total = d.M / 32;
+  a.min_off = d.min_off;
+  a.width = d.max_off - d.min_off;
+  for (int c = 0; c < 2; ++c) {
+    a.toff0[c] = d.toff0[c];
+    a.tstep[c] = d.tstep[c];
+  }
+  const int L = a.L, M = d.M;
+  switch (d.mode) {
+    case MODE_PLAIN:
+      if (M % 64 == 0) {
+        if (L <= 96 && M % 128 == 0) return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, stream);
+        return launch_cfg<2, 2, 1, 4, MODE_PLAIN>(a, stream);
+      }
+      if (L > 1024) return launch_cfg<1, 4, 1, 4, MODE_PLAIN>(a, stream);
+      if (L > 192) return launch_cfg<1, 2, 1, 4, MODE_PLAIN>(a, stream);
+      return launch_cfg<1, 1, 1, 4, MODE_PLAIN>(a, stream);
+    case MODE_GATE:
+      if (M % 64 != 0) return hipErrorInvalidValue;
+      if (L <= 96) return launch_cfg<2, 1, 2, 2, MODE_GATE>(a, stream);
+      return launch_cfg<2, 2, 1, 4, MODE_GATE>(a, stream);
+    case MODE_UP8:
+      if (M % 64 != 0) return hipErrorInvalidValue;
+      if (L <= 1024) return launch_cfg<2, 1, 2, 2, MODE_UP8>(a, stream);
+      return launch_cfg<2, 2, 1, 4, MODE_UP8>(a, stream);
+    case MODE_UP4:
+      if (M % 64 != 0) return hipErrorInvalidValue;
+      return launch_cfg<2, 2, 1, 4, MODE_UP4>(a, stream);
+    case MODE_UP2:
+      if (M % 64 != 0) return hipErrorInvalidValue;
+      return launch_cfg<2, 2, 1, 4, MODE_UP2>(a, stream);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace vits

@@ -1,0 +1,514 @@
+// Bandwidth-bound and small kernels of the MVTS synthesis path (gfx950, wave64): channel-first LayerNorm,
+// windowed relative-position attention, length regulator (prefix sum + gather), embeddings, conditioning GEMV,
+// 1-channel convs and the scalar control math.  Every kernel reads and writes with lanes on the time axis, the
+// contiguous axis of the [B, C, L] layout, so global accesses are coalesced.
+#include "common.h"
+#include <math.h>
+
+namespace vits {
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm over channels of [B, C, L]  (reference modules.py:15-27; nn.LayerNorm in frame_prior_network.py:83,95)
+// biased variance, eps inside the sqrt.  Block = 64 time steps x 4 waves splitting the channels.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const int* __restrict__ lengths, int C, int L, int mask_out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t = blockIdx.x * 64 + lane;
+  const bool valid = t < L;
+  const float* xb = x + (long long)b * C * L + t;
+  float* yb = y + (long long)b * C * L + t;
+  float s = 0.f;
+  for (int c = wave; c < C; c += 4) s += valid ? xb[(long long)c * L] : 0.f;
+  red[wave][lane] = s;
+  __syncthreads();
+  const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  __syncthreads();
+  s = 0.f;
+  for (int c = wave; c < C; c += 4) {
+    const float d = (valid ? xb[(long long)c * L] : 0.f) - mean;
+    s += d * d;
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  const float rstd = 1.f / sqrtf(var + 1e-5f);
+  const bool keep = !mask_out || (lengths && t < lengths[b]) || !lengths;
+  if (valid) {
+    for (int c = wave; c < C; c += 4) {
+      const float v = (xb[(long long)c * L] - mean) * rstd * gamma[c] + beta[c];
+      yb[(long long)c * L] = keep ? v : 0.f;
+    }
+  }
+}
+
+hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta, const int* lengths,
+                             int B, int C, int L, bool mask_out, hipStream_t s) {
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535) return hipErrorInvalidValue;
+  dim3 grid((L + 63) / 64, B);
+  hipLaunchKernelGGL(layer_norm_kernel, grid, dim3(256), 0, s, x, y, gamma, beta, lengths, C, L, mask_out ? 1 : 0);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Self-attention with windowed relative-position keys/values (reference attentions.py:226-257, banded form):
+//   s_ij = (q_i/sqrt(dk)).k_j + [|j-i|<=W] (q_i/sqrt(dk)).Ek[j-i+W];   masked (i or j beyond the length) -> -1e4
+//   p = softmax_j(s);   o_i = sum_j p_ij v_j + sum_{|j-i|<=W} p_ij Ev[j-i+W]
+// qkv is [B, 3*H*DK, L] (q rows, then k rows, then v rows).  A block handles 16 queries of one (batch, head):
+// each wave owns 4 queries, lanes run over keys, scores for the whole row stay in registers (NCH chunks of 64).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int ATT_DK = 96;
+constexpr int ATT_W = 4;
+
+template <int NCH>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, const float* __restrict__ ek,
+                                                         const float* __restrict__ ev,
+                                                         const int* __restrict__ lengths, float* __restrict__ out,
+                                                         int H, int L) {
+  constexpr int DK = ATT_DK, W = ATT_W, NR = 2 * ATT_W + 1;
+  __shared__ __attribute__((aligned(16))) float q_s[DK][16];
+  __shared__ float qe_s[16][NR];
+  __shared__ float pw_s[16][NR];
+  __shared__ float o_s[16][DK + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+  const int C = H * DK;
+  const int len = lengths ? lengths[b] : L;
+  const float* qb = qkv + ((long long)b * 3 * C + h * DK) * L;
+  const float* kb = qb + (long long)C * L;
+  const float* vb = kb + (long long)C * L;
+  const float inv = sqrtf((float)DK);
+
+  for (int idx = tid; idx < DK * 16; idx += 256) {
+    const int c = idx >> 4, qi = idx & 15, i = i0 + qi;
+    q_s[c][qi] = i < L ? qb[(long long)c * L + i] / inv : 0.f;
+  }
+  if (tid < 16 * NR) pw_s[tid / NR][tid % NR] = 0.f;
+  __syncthreads();
+  if (tid < 16 * NR) {
+    const int qi = tid / NR, r = tid % NR;
+    float s = 0.f;
+    for (int c = 0; c < DK; ++c) s += q_s[c][qi] * ek[r * DK + c];
+    qe_s[qi][r] = s;
+  }
+  __syncthreads();
+
+  const int qw = wave * 4;
+  float sc[4][NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int j = ch * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (ch * 64 < L) {
+      const bool jv = j < L;
+      const float* kp = kb + (jv ? j : 0);
+#pragma unroll 8
+      for (int c = 0; c < DK; ++c) {
+        const float kv = kp[(long long)c * L];
+        const float4 q4 = *reinterpret_cast<const float4*>(&q_s[c][qw]);
+        a0 += q4.x * kv;
+        a1 += q4.y * kv;
+        a2 += q4.z * kv;
+        a3 += q4.w * kv;
+      }
+      float av[4] = {a0, a1, a2, a3};
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int i = i0 + qw + n;
+        const int r = j - i + W;
+        float v = av[n];
+        if (r >= 0 && r < NR) v += qe_s[qw + n][r];
+        if (!(i < len && j < len)) v = -1e4f;
+        sc[n][ch] = jv ? v : -INFINITY;
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) sc[n][ch] = -INFINITY;
+    }
+  }
+  // softmax over the row (all chunks, all lanes)
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) m = fmaxf(m, sc[n][ch]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const float e = expf(sc[n][ch] - m);     // exp(-inf) = 0 for keys beyond L
+      sc[n][ch] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float rinv = 1.f / sum;
+    const int i = i0 + qw + n;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const float p = sc[n][ch] * rinv;
+      sc[n][ch] = p;
+      const int j = ch * 64 + lane, r = j - i + W;
+      if (r >= 0 && r < NR && j < L) pw_s[qw + n][r] = p;
+    }
+  }
+  // o = p . v  (per channel: lanes hold partial sums over their keys, then a wave reduction)
+  for (int c = 0; c < DK; ++c) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* vp = vb + (long long)c * L;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int j = ch * 64 + lane;
+      if (ch * 64 < L) {
+        const float vv = j < L ? vp[j] : 0.f;
+        a0 += sc[0][ch] * vv;
+        a1 += sc[1][ch] * vv;
+        a2 += sc[2][ch] * vv;
+        a3 += sc[3][ch] * vv;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a0 += __shfl_xor(a0, o);
+      a1 += __shfl_xor(a1, o);
+      a2 += __shfl_xor(a2, o);
+      a3 += __shfl_xor(a3, o);
+    }
+    if (lane == 0) {
+      o_s[qw + 0][c] = a0;
+      o_s[qw + 1][c] = a1;
+      o_s[qw + 2][c] = a2;
+      o_s[qw + 3][c] = a3;
+    }
+  }
+  __syncthreads();
+  float* ob = out + ((long long)b * C + h * DK) * L;
+  for (int idx = tid; idx < DK * 16; idx += 256) {
+    const int c = idx >> 4, qi = idx & 15, i = i0 + qi;
+    if (i < L) {
+      float v = o_s[qi][c];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) v += pw_s[qi][r] * ev[r * DK + c];
+      ob[(long long)c * L + i] = v;
+    }
+  }
+}
+
+hipError_t launch_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
+                            int B, int H, int DK, int L, int window, hipStream_t s) {
+  if (DK != ATT_DK || window != ATT_W || B <= 0 || L <= 0 || L > 2048 || B > 65535) return hipErrorInvalidValue;
+  dim3 grid((L + 15) / 16, H, B);
+  const int nch = (L + 63) / 64;
+#define ATT_LAUNCH(N) hipLaunchKernelGGL(attention_kernel<N>, grid, dim3(256), 0, s, qkv, emb_k, emb_v, lengths, out, H, L)
+  if (nch <= 2) ATT_LAUNCH(2);
+  else if (nch <= 4) ATT_LAUNCH(4);
+  else if (nch <= 8) ATT_LAUNCH(8);
+  else if (nch <= 16) ATT_LAUNCH(16);
+  else ATT_LAUNCH(32);
+#undef ATT_LAUNCH
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// embedding lookups and conditioning
+// ---------------------------------------------------------------------------------------------------------
+// x[b][c][p] = table[ids[b][p]][c] * sqrt(C) * (p < len[b])     (reference models.py:176-180)
+__global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                             const int* __restrict__ lengths, float* __restrict__ x, int B, int P, int C, int n_vocab,
+                             int* err_flag) {
+  const long long n = (long long)B * C * P;
+  const float scale = sqrtf((float)C);
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+    const int p = idx % P;
+    const int c = (idx / P) % C;
+    const int b = idx / ((long long)P * C);
+    long long id = ids[(long long)b * P + p];
+    if (id < 0 || id >= n_vocab) {
+      if (err_flag) atomicOr(err_flag, 1);
+      id = 0;
+    }
+    x[idx] = p < lengths[b] ? table[id * C + c] * scale : 0.f;
+  }
+}
+
+hipError_t launch_embed(const int64_t* ids, const float* table, const int* lengths, float* x, int B, int P, int C,
+                        int n_vocab, int* err_flag, hipStream_t s) {
+  const long long n = (long long)B * C * P;
+  if (n <= 0) return hipErrorInvalidValue;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(embed_kernel, dim3(blocks), dim3(256), 0, s, ids, table, lengths, x, B, P, C, n_vocab, err_flag);
+  return hipGetLastError();
+}
+
+// out[b][row] = bias[row] + sum_ci w[row][ci] * emb_g[sid[b]][ci]: every 1x1 conditioning conv on the speaker
+// embedding (reference models.py:129,282-287,551,719-720; modules.py:149; frame_prior_network.py:126) in one launch.
+__global__ __launch_bounds__(256) void cond_gemv_kernel(const float* __restrict__ emb_g, const int64_t* __restrict__ sid,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int rows, int gin, int n_speakers,
+                                                         int* err_flag) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave, b = blockIdx.y;
+  if (row >= rows) return;
+  long long sp = sid[b];
+  if (sp < 0 || sp >= n_speakers) {
+    if (err_flag && lane == 0) atomicOr(err_flag, 2);
+    sp = 0;
+  }
+  const float* g = emb_g + sp * gin;
+  const float* wr = w + (long long)row * gin;
+  float s = 0.f;
+  for (int c = lane; c < gin; c += 64) s += wr[c] * g[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[(long long)b * rows + row] = s + bias[row];
+}
+
+hipError_t launch_cond_gemv(const float* emb_g, const int64_t* sid, const float* w, const float* bias, float* out,
+                            int B, int rows, int gin, int n_speakers, int* err_flag, hipStream_t s) {
+  if (B <= 0 || rows <= 0 || B > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cond_gemv_kernel, dim3((rows + 3) / 4, B), dim3(256), 0, s, emb_g, sid, w, bias, out, rows, gin,
+                     n_speakers, err_flag);
+  return hipGetLastError();
+}
+
+// y[b][c][t] = (x[b][c][t] + cb[b][c]) * (mask ? t < len[b] : 1)      (reference models.py:551-553)
+__global__ void add_cbias_mask_kernel(const float* __restrict__ x, const float* __restrict__ cb, int cb_bs,
+                                      const int* __restrict__ lengths, float* __restrict__ y, int B, int C, int L,
+                                      int mask) {
+  const long long n = (long long)B * C * L;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+    const int t = idx % L;
+    const int c = (idx / L) % C;
+    const int b = idx / ((long long)L * C);
+    const float v = x[idx] + cb[(long long)b * cb_bs + c];
+    y[idx] = (!mask || t < lengths[b]) ? v : 0.f;
+  }
+}
+
+hipError_t launch_add_cbias_mask(const float* x, const float* cb, int cb_bs, const int* lengths, float* y, int B, int C,
+                                 int L, bool mask, hipStream_t s) {
+  const long long n = (long long)B * C * L;
+  if (n <= 0) return hipErrorInvalidValue;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(add_cbias_mask_kernel, dim3(blocks), dim3(256), 0, s, x, cb, cb_bs, lengths, y, B, C, L,
+                     mask ? 1 : 0);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv with ONE output channel: out[b][t] = act(bias + sum_{c,k} w[c*K+k] * pro(x[b][c][t+k-(K-1)/2]))
+// (reference models.py:120 duration proj, :543 proj_f0, :278 conv_post; frame_prior_network.py:101 linear_layer)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_to1_kernel(const float* __restrict__ x, long long x_bs, int x_cs,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ out, const int* __restrict__ lengths, int C,
+                                                        int K, int L, int flags, float in_scale, float in_slope,
+                                                        int tanh_out, int mask_out) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= L) return;
+  const int len = lengths ? lengths[b] : 0x7fffffff;
+  const int pad = (K - 1) / 2;
+  const float* xb = x + (long long)b * x_bs;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* xr = xb + (long long)c * x_cs;
+    for (int k = 0; k < K; ++k) {
+      const int tt = t + k - pad;
+      bool ok = tt >= 0 && tt < L;
+      if (flags & F_IN_MASK) ok = ok && tt < len;
+      float v = ok ? xr[tt] * in_scale : 0.f;
+      if (flags & F_IN_LRELU) v = v > 0.f ? v : v * in_slope;
+      acc += w[c * K + k] * v;
+    }
+  }
+  if (bias) acc += bias[0];
+  if (tanh_out) acc = tanhf(acc);
+  if (mask_out && t >= len) acc = 0.f;
+  out[(long long)b * L + t] = acc;
+}
+
+hipError_t launch_conv_to1(const float* x, long long x_bs, int x_cs, const float* w, const float* bias, float* out,
+                           const int* lengths, int B, int C, int K, int L, int flags, float in_scale, float in_slope,
+                           bool tanh_out, bool mask_out, hipStream_t s) {
+  if (B <= 0 || L <= 0 || B > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(conv_to1_kernel, dim3((L + 255) / 256, B), dim3(256), 0, s, x, x_bs, x_cs, w, bias, out, lengths,
+                     C, K, L, flags, in_scale, in_slope, tanh_out ? 1 : 0, mask_out ? 1 : 0);
+  return hipGetLastError();
+}
+
+// x[b][c][t] += bias[c] + sum_k w[c*3+k] * sig[b][t+k-1]   (zero padded; reference models.py:657-658,742,752)
+__global__ void prenet_add_kernel(float* __restrict__ x, const float* __restrict__ sig, const float* __restrict__ w,
+                                  const float* __restrict__ bias, int B, int C, int L) {
+  const long long n = (long long)B * C * L;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+    const int t = idx % L;
+    const int c = (idx / L) % C;
+    const int b = idx / ((long long)L * C);
+    const float* sb = sig + (long long)b * L;
+    const float s0 = t > 0 ? sb[t - 1] : 0.f, s1 = sb[t], s2 = t + 1 < L ? sb[t + 1] : 0.f;
+    x[idx] += (w[c * 3] * s0 + w[c * 3 + 1] * s1 + w[c * 3 + 2] * s2) + bias[c];
+  }
+}
+
+hipError_t launch_prenet_add(float* x, const float* sig, const float* w, const float* bias, int B, int C, int L,
+                             hipStream_t s) {
+  const long long n = (long long)B * C * L;
+  if (n <= 0) return hipErrorInvalidValue;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(prenet_add_kernel, dim3(blocks), dim3(256), 0, s, x, sig, w, bias, B, C, L);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scalar control math  (reference models.py:732-733, 737-743, 747-753, 763)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void duration_finalize_kernel(const float* __restrict__ logw, const int* __restrict__ lengths, float scale,
+                                         float* __restrict__ dur, int B, int P) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * P) return;
+  const int b = idx / P, p = idx % P;
+  const float m = p < lengths[b] ? 1.f : 0.f;
+  dur[idx] = ceilf((expf(logw[idx]) * m - 1.f) * scale);
+}
+
+hipError_t launch_duration_finalize(const float* logw, const int* lengths, float scale, float* dur, int B, int P,
+                                    hipStream_t s) {
+  hipLaunchKernelGGL(duration_finalize_kernel, dim3((B * P + 255) / 256), dim3(256), 0, s, logw, lengths, scale, dur, B, P);
+  return hipGetLastError();
+}
+
+__global__ void pitch_math_kernel(const float* __restrict__ in, int in_is_hz, float scale, float* __restrict__ lf0,
+                                  float* __restrict__ f0, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float v = in[idx];
+  const float l = in_is_hz ? (2595.f * log10f(1.f + v / 700.f)) / 500.f : v * scale;
+  lf0[idx] = l;
+  f0[idx] = (powf(10.f, l * 500.f / 2590.f) - 1.f) * 700.f;      // 2590, not 2595: as the reference (models.py:743)
+}
+
+hipError_t launch_pitch_math(const float* in, bool in_is_hz, float scale, float* lf0, float* f0, int n, hipStream_t s) {
+  hipLaunchKernelGGL(pitch_math_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, in_is_hz ? 1 : 0, scale, lf0, f0, n);
+  return hipGetLastError();
+}
+
+__global__ void energy_math_kernel(const float* __restrict__ in, int in_is_raw, float scale, float* __restrict__ norm,
+                                   float* __restrict__ energy, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float v = in[idx];
+  const float ne = in_is_raw ? (v - 60.f) / 36.f : (((v * 36.f + 60.f) * scale) - 60.f) / 36.f;
+  norm[idx] = ne;
+  energy[idx] = ne * 36.f + 60.f;
+}
+
+hipError_t launch_energy_math(const float* in, bool in_is_raw, float scale, float* norm, float* energy, int n,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(energy_math_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, in_is_raw ? 1 : 0, scale, norm,
+                     energy, n);
+  return hipGetLastError();
+}
+
+// z_p = m_p + noise * exp(logs_p) * noise_scale, with stats = [B, 2C, L] holding m_p then logs_p; z gets a copy.
+__global__ void sample_kernel(const float* __restrict__ stats, const float* __restrict__ noise, float noise_scale,
+                              float* __restrict__ z_p, float* __restrict__ z, int B, int C, int L) {
+  const long long n = (long long)B * C * L;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+    const long long cl = idx % ((long long)C * L);
+    const long long b = idx / ((long long)C * L);
+    const float m = stats[b * 2 * C * L + cl];
+    const float ls = stats[b * 2 * C * L + (long long)C * L + cl];
+    const float v = m + noise[idx] * expf(ls) * noise_scale;
+    z_p[idx] = v;
+    z[idx] = v;
+  }
+}
+
+hipError_t launch_sample(const float* stats, const float* noise, float noise_scale, float* z_p, float* z, int B, int C,
+                         int L, hipStream_t s) {
+  const long long n = (long long)B * C * L;
+  if (n <= 0) return hipErrorInvalidValue;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(sample_kernel, dim3(blocks), dim3(256), 0, s, stats, noise, noise_scale, z_p, z, B, C, L);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// length regulator (reference models.py:426-455): phoneme p of row b is repeated max(int(dur[b][p]), 0) times.
+// plan: integer durations -> inclusive prefix sum per row (block scan in LDS);  gather: per frame, binary search
+// of the prefix sums, then a coalesced copy of the phoneme's channel vector.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LR_MAX_P = 2048;
+
+__device__ inline int dur_to_int(const void* dur, int dtype, long long i) {
+  long long v;
+  switch (dtype) {
+    case 0: { const float f = ((const float*)dur)[i]; v = (long long)f; break; }     // int(): truncation
+    case 1: v = ((const int64_t*)dur)[i]; break;
+    case 2: v = ((const int*)dur)[i]; break;
+    default: { const double f = ((const double*)dur)[i]; v = (long long)f; break; }
+  }
+  if (v < 0) v = 0;
+  if (v > (1 << 24)) v = 1 << 24;
+  return (int)v;
+}
+
+__global__ __launch_bounds__(256) void lr_plan_kernel(const void* __restrict__ dur, int dtype, int P,
+                                                       int* __restrict__ cum, int* __restrict__ totals) {
+  __shared__ int buf[2][LR_MAX_P];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int p = tid; p < P; p += 256) buf[0][p] = dur_to_int(dur, dtype, (long long)b * P + p);
+  __syncthreads();
+  int cur = 0;
+  for (int off = 1; off < P; off <<= 1) {
+    for (int p = tid; p < P; p += 256) buf[cur ^ 1][p] = buf[cur][p] + (p >= off ? buf[cur][p - off] : 0);
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (int p = tid; p < P; p += 256) cum[(long long)b * P + p] = buf[cur][p];
+  if (tid == 0) totals[b] = buf[cur][P - 1];
+}
+
+hipError_t launch_lr_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, hipStream_t s) {
+  if (B <= 0 || P <= 0 || P > LR_MAX_P || dur_dtype < 0 || dur_dtype > 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lr_plan_kernel, dim3(B), dim3(256), 0, s, dur, dur_dtype, P, cum, totals);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void lr_gather_kernel(const float* __restrict__ x, const int* __restrict__ cum,
+                                                         const int* __restrict__ totals, float* __restrict__ out, int C,
+                                                         int P, int T) {
+  __shared__ int cs[LR_MAX_P];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int p = tid; p < P; p += 256) cs[p] = cum[(long long)b * P + p];
+  __syncthreads();
+  const int t = blockIdx.x * 256 + tid;
+  if (t >= T) return;
+  const int total = totals[b];
+  int src = -1;
+  if (t < total) {               // first p with cum[p] > t
+    int lo = 0, hi = P - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cs[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    src = lo;
+  }
+  const float* xb = x + (long long)b * C * P;
+  float* ob = out + (long long)b * C * T + t;
+  for (int c = 0; c < C; ++c) ob[(long long)c * T] = src >= 0 ? xb[(long long)c * P + src] : 0.f;
+}
+
+hipError_t launch_lr_gather(const float* x, const int* cum, const int* totals, float* out, int B, int C, int P, int T,
+                            hipStream_t s) {
+  if (B <= 0 || P <= 0 || P > LR_MAX_P || T <= 0 || B > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lr_gather_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, x, cum, totals, out, C, P, T);
+  return hipGetLastError();
+}
+
+}  // namespace vits

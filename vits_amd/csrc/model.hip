@@ -1,0 +1,630 @@
+// Host side of libvits_amd.so: model registry, stage orchestration and the C ABI declared in include/vits_amd.h.
+// Each stage function enqueues hand-written kernels (kernels_conv.hip, kernels_misc.hip) on the caller's stream and
+// allocates nothing; activations live in the caller's workspace.
+#include "common.h"
+#include "../../include/vits_amd.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace vits;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(VITS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+struct Plain {
+  const float* p = nullptr;
+  int64_t n = 0;
+};
+
+struct EncLayer {
+  ConvDesc qkv, o, ffn1, ffn2;
+  const float *ek, *ev, *ln1g, *ln1b, *ln2g, *ln2b;
+};
+
+struct FlowLayer {
+  ConvDesc pre, post;
+  std::vector<ConvDesc> in, res, skip;
+};
+
+struct ResBlock {
+  std::vector<ConvDesc> c1, c2;
+};
+
+}  // namespace
+
+struct vits_model {
+  vits_config cfg{};
+  std::map<std::string, Plain> plain;
+  std::map<std::string, ConvDesc> convs;
+  bool finalized = false;
+  // resolved
+  std::vector<EncLayer> enc[3];
+  const float *symbol_emb = nullptr, *emb_g = nullptr, *cond_w = nullptr, *cond_b = nullptr;
+  ConvDesc dp_conv1, dp_conv2, en_conv1, en_conv2, project, conv_pre;
+  const float *dp_ln1g, *dp_ln1b, *dp_ln2g, *dp_ln2b, *dp_proj_w, *dp_proj_b;
+  const float *pitch_proj_w, *pitch_proj_b, *pitch_pre_w, *pitch_pre_b;
+  const float *en_ln1g, *en_ln1b, *en_ln2g, *en_ln2b, *en_lin_w, *en_lin_b, *en_pre_w, *en_pre_b;
+  std::vector<FlowLayer> flows;
+  std::vector<ConvDesc> ups;
+  std::vector<ResBlock> rbs;
+  const float* conv_post_w = nullptr;
+  int cond_rows = 0, off_dp = 0, off_pitch = 0, off_energy = 0, off_dec = 0, off_flow = 0;
+  int total_up = 1;
+};
+
+namespace {
+
+const char* kEncNames[3] = {"enc_p.encoder", "pitch_predictor.pitch_net", "frame_prior_net.fft_block"};
+
+struct Arena {
+  char* base;
+  int64_t size, used = 0;
+  Arena(void* p, int64_t n) : base((char*)p), size(n) {}
+  float* take(int64_t floats) {
+    const int64_t bytes = (floats * 4 + 255) & ~int64_t(255);
+    if (used + bytes > size) return nullptr;
+    float* r = (float*)(base + used);
+    used += bytes;
+    return r;
+  }
+};
+
+inline int64_t pad256(int64_t floats) { return (floats * 4 + 255) & ~int64_t(255); }
+
+int make_desc(ConvDesc& d, const float* w, const float* bias, int cin, int rows, int taps, int dilation, int mode) {
+  if (cin <= 0 || cin % CI_CHUNK || rows <= 0 || rows % 32 || taps < 1 || taps > MAX_TAPS || dilation < 1)
+    return fail(VITS_ERR_INVALID, "conv: cin must be a multiple of 16, rows of 32, 1 <= taps <= 12");
+  d = ConvDesc();
+  d.w = w;
+  d.bias = bias;
+  d.Cin = cin;
+  d.M = rows;
+  d.K = taps;
+  d.mode = mode;
+  switch (mode) {
+    case MODE_PLAIN:
+    case MODE_GATE:
+      if (mode == MODE_GATE && rows % 64) return fail(VITS_ERR_INVALID, "gated conv: rows must be a multiple of 64");
+      d.toff0[0] = d.toff0[1] = -((taps - 1) / 2) * dilation;
+      d.tstep[0] = d.tstep[1] = dilation;
+      d.min_off = d.toff0[0];
+      d.max_off = d.toff0[0] + (taps - 1) * dilation;
+      d.up = 1;
+      d.cout = mode == MODE_GATE ? rows / 2 : rows;
+      break;
+    case MODE_UP8:
+    case MODE_UP2:
+      // stride u, kernel 2u, padding u/2: phase r < u/2 reads x[t], x[t-1]; phase r >= u/2 reads x[t+1], x[t]
+      if (taps != 2 || rows % 64) return fail(VITS_ERR_INVALID, "transposed conv (stride 8 / 2): taps must be 2, rows % 64 == 0");
+      d.toff0[0] = 0; d.tstep[0] = -1;
+      d.toff0[1] = 1; d.tstep[1] = -1;
+      d.min_off = -1; d.max_off = 1;
+      d.up = mode == MODE_UP8 ? 8 : 2;
+      d.cout = rows / d.up;
+      break;
+    case MODE_UP4:
+      if (taps != 1 || rows % 64) return fail(VITS_ERR_INVALID, "transposed conv (stride 4): taps must be 1, rows % 64 == 0");
+      d.up = 4;
+      d.cout = rows / 4;
+      break;
+    default:
+      return fail(VITS_ERR_INVALID, "conv: unknown mode");
+  }
+  if (d.max_off - d.min_off > MAX_HALO) return fail(VITS_ERR_INVALID, "conv: receptive field wider than 64 samples");
+  return VITS_OK;
+}
+
+ConvArgs base_args(const float* x, long long x_bs, int x_cs, float* out, long long out_bs, int out_cs, int B, int L,
+                   const int* lengths, int flags) {
+  ConvArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x; a.x_bs = x_bs; a.x_cs = x_cs;
+  a.out = out; a.out_bs = out_bs; a.out_cs = out_cs;
+  a.B = B; a.L = L; a.lengths = lengths; a.flags = flags;
+  a.in_scale = 1.f; a.in_slope = 1.f;
+  return a;
+}
+
+// contiguous [B, Cin, L] -> [B, cout, L*up]
+int conv_simple(const ConvDesc& d, const float* x, float* out, int B, int L, const int* lengths, int flags,
+                hipStream_t s, const float* res = nullptr, const float* cbias = nullptr, int cbias_bs = 0,
+                const float* in_cbias = nullptr, int in_cbias_bs = 0, float in_scale = 1.f, float in_slope = 1.f) {
+  ConvArgs a = base_args(x, (long long)d.Cin * L, L, out, (long long)d.cout * L * d.up, L * d.up, B, L, lengths, flags);
+  a.res = res; a.res_bs = (long long)d.cout * L; a.res_cs = L;
+  a.cbias = cbias; a.cbias_bs = cbias_bs;
+  a.in_cbias = in_cbias; a.in_cbias_bs = in_cbias_bs;
+  a.in_scale = in_scale; a.in_slope = in_slope;
+  HIP_TRY(launch_conv(d, a, s));
+  return VITS_OK;
+}
+
+#define TRY(expr)            \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != VITS_OK) return rc_; \
+  } while (0)
+
+int64_t encoder_ws_floats(const vits_model* m, int B, int L) {
+  const int64_t C = m->cfg.hidden_channels, F = m->cfg.filter_channels;
+  return (pad256((int64_t)B * 3 * C * L) + pad256((int64_t)B * C * L) + pad256((int64_t)B * F * L)) / 4;
+}
+
+int run_encoder(const vits_model* m, int which, float* x, const int* lengths, int B, int L, Arena& ar, hipStream_t s) {
+  const int C = m->cfg.hidden_channels, F = m->cfg.filter_channels, H = m->cfg.n_heads;
+  float* qkv = ar.take((int64_t)B * 3 * C * L);
+  float* att = ar.take((int64_t)B * C * L);
+  float* h = ar.take((int64_t)B * F * L);
+  if (!qkv || !att || !h) return fail(VITS_ERR_WORKSPACE, "encoder: workspace too small");
+  const auto& layers = m->enc[which];
+  for (size_t i = 0; i < layers.size(); ++i) {
+    const EncLayer& l = layers[i];
+    TRY(conv_simple(l.qkv, x, qkv, B, L, lengths, 0, s));
+    HIP_TRY(launch_attention(qkv, l.ek, l.ev, lengths, att, B, H, C / H, L, m->cfg.window_size, s));
+    TRY(conv_simple(l.o, att, x, B, L, lengths, F_RES, s, x));
+    HIP_TRY(launch_layer_norm(x, x, l.ln1g, l.ln1b, lengths, B, C, L, false, s));
+    TRY(conv_simple(l.ffn1, x, h, B, L, lengths, F_IN_MASK | F_RELU, s));
+    TRY(conv_simple(l.ffn2, h, x, B, L, lengths, F_IN_MASK | F_MASK_PRE | F_RES, s, x));
+    HIP_TRY(launch_layer_norm(x, x, l.ln2g, l.ln2b, lengths, B, C, L, i + 1 == layers.size(), s));
+  }
+  return VITS_OK;
+}
+
+const float* need_plain(vits_model* m, const std::string& name, int64_t numel, std::string& missing) {
+  auto it = m->plain.find(name);
+  if (it == m->plain.end() || (numel > 0 && it->second.n != numel)) {
+    if (missing.empty()) missing = name + (it == m->plain.end() ? " (not set)" : " (wrong size)");
+    return nullptr;
+  }
+  return it->second.p;
+}
+
+ConvDesc need_conv(vits_model* m, const std::string& name, int cin, int rows, int taps, int mode, std::string& missing) {
+  auto it = m->convs.find(name);
+  if (it == m->convs.end()) {
+    if (missing.empty()) missing = name + " (conv not set)";
+    return ConvDesc();
+  }
+  const ConvDesc& d = it->second;
+  if (d.Cin != cin || d.M != rows || d.K != taps || d.mode != mode) {
+    if (missing.empty()) {
+      char buf[256];
+      snprintf(buf, sizeof buf, "%s (conv shape: got cin %d rows %d taps %d mode %d, need %d %d %d %d)", name.c_str(),
+               d.Cin, d.M, d.K, d.mode, cin, rows, taps, mode);
+      missing = buf;
+    }
+    return ConvDesc();
+  }
+  return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vits_last_error(void) { return g_err.c_str(); }
+const char* vits_version(void) { return "vits_amd 0.1 (gfx950, fp32 MFMA)"; }
+
+int vits_model_create(const vits_config* cfg, vits_model** out) {
+  if (!cfg || !out) return fail(VITS_ERR_INVALID, "null argument");
+  const vits_config& c = *cfg;
+  if (c.hidden_channels != c.inter_channels) return fail(VITS_ERR_INVALID, "hidden_channels must equal inter_channels");
+  if (c.hidden_channels % 32 || c.filter_channels % 32 || c.dur_filter % 32 || c.energy_filter % 32)
+    return fail(VITS_ERR_INVALID, "channel counts must be multiples of 32");
+  if (c.n_heads <= 0 || c.hidden_channels / c.n_heads != 96 || c.window_size != 4)
+    return fail(VITS_ERR_INVALID, "attention kernel is built for head dim 96 and window 4");
+  if (c.n_flows <= 0 || c.n_flows % 2) return fail(VITS_ERR_INVALID, "n_flows must be even (channel flips are folded into weights)");
+  if ((c.inter_channels / 2) % CI_CHUNK) return fail(VITS_ERR_INVALID, "inter_channels / 2 must be a multiple of 16");
+  if (c.n_upsamples <= 0 || c.n_upsamples > 8 || c.n_resblock_kernels <= 0 || c.n_resblock_kernels > 8 ||
+      c.n_resblock_dilations <= 0 || c.n_resblock_dilations > 8)
+    return fail(VITS_ERR_INVALID, "generator: bad upsample / resblock counts");
+  if (c.gin_channels <= 0 || c.n_speakers <= 1) return fail(VITS_ERR_INVALID, "a speaker-conditioned model is required (n_speakers > 1, gin_channels > 0)");
+  for (int i = 0; i < c.n_upsamples; ++i) {
+    const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+    if (!((u == 8 && k == 16) || (u == 4 && k == 4) || (u == 2 && k == 4)))
+      return fail(VITS_ERR_INVALID, "generator: supported (stride, kernel) pairs are (8,16), (4,4), (2,4)");
+    if ((c.upsample_initial_channel >> (i + 1)) % 32) return fail(VITS_ERR_INVALID, "generator: channels must stay multiples of 32");
+  }
+  vits_model* m = new vits_model();
+  m->cfg = c;
+  *out = m;
+  return VITS_OK;
+}
+
+void vits_model_destroy(vits_model* m) { delete m; }
+
+int vits_model_set_tensor(vits_model* m, const char* name, const float* p, int64_t numel) {
+  if (!m || !name || !p || numel <= 0) return fail(VITS_ERR_INVALID, "set_tensor: bad argument");
+  m->plain[name] = Plain{p, numel};
+  m->finalized = false;
+  return VITS_OK;
+}
+
+int vits_model_set_conv(vits_model* m, const char* name, const float* w, const float* bias, int cin, int rows, int taps,
+                        int dilation, int mode) {
+  if (!m || !name || !w) return fail(VITS_ERR_INVALID, "set_conv: bad argument");
+  ConvDesc d;
+  TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode));
+  m->convs[name] = d;
+  m->finalized = false;
+  return VITS_OK;
+}
+
+int vits_model_finalize(vits_model* m) {
+  if (!m) return fail(VITS_ERR_INVALID, "null model");
+  const vits_config& c = m->cfg;
+  const int C = c.hidden_channels, F = c.filter_channels, G = c.gin_channels, half = c.inter_channels / 2;
+  const int NR = 2 * c.window_size + 1, DK = C / c.n_heads;
+  std::string miss;
+  m->symbol_emb = need_plain(m, "enc_p.symbol_emb", (int64_t)c.n_vocab * C, miss);
+  m->emb_g = need_plain(m, "emb_g", (int64_t)c.n_speakers * G, miss);
+  const int ch0 = c.upsample_initial_channel;
+  m->off_dp = 0; m->off_pitch = C; m->off_energy = 2 * C; m->off_dec = 3 * C; m->off_flow = 3 * C + ch0;
+  m->cond_rows = m->off_flow + c.n_flows * 2 * C * c.flow_layers;
+  m->cond_w = need_plain(m, "cond.w", (int64_t)m->cond_rows * G, miss);
+  m->cond_b = need_plain(m, "cond.b", m->cond_rows, miss);
+  const int nlayers[3] = {c.n_layers, c.pitch_layers, c.n_layers};
+  for (int e = 0; e < 3; ++e) {
+    m->enc[e].clear();
+    for (int i = 0; i < nlayers[e]; ++i) {
+      const std::string p = std::string(kEncNames[e]) + "." + std::to_string(i);
+      EncLayer l;
+      l.qkv = need_conv(m, p + ".qkv", C, 3 * C, 1, MODE_PLAIN, miss);
+      l.o = need_conv(m, p + ".o", C, C, 1, MODE_PLAIN, miss);
+      l.ffn1 = need_conv(m, p + ".ffn1", C, F, c.kernel_size, MODE_PLAIN, miss);
+      l.ffn2 = need_conv(m, p + ".ffn2", F, C, c.kernel_size, MODE_PLAIN, miss);
+      l.ek = need_plain(m, p + ".emb_rel_k", (int64_t)NR * DK, miss);
+      l.ev = need_plain(m, p + ".emb_rel_v", (int64_t)NR * DK, miss);
+      l.ln1g = need_plain(m, p + ".ln1.g", C, miss);
+      l.ln1b = need_plain(m, p + ".ln1.b", C, miss);
+      l.ln2g = need_plain(m, p + ".ln2.g", C, miss);
+      l.ln2b = need_plain(m, p + ".ln2.b", C, miss);
+      m->enc[e].push_back(l);
+    }
+  }
+  const int DF = c.dur_filter, EF = c.energy_filter;
+  m->dp_conv1 = need_conv(m, "dp.conv1", C, DF, 3, MODE_PLAIN, miss);
+  m->dp_conv2 = need_conv(m, "dp.conv2", DF, DF, 3, MODE_PLAIN, miss);
+  m->dp_ln1g = need_plain(m, "dp.ln1.g", DF, miss); m->dp_ln1b = need_plain(m, "dp.ln1.b", DF, miss);
+  m->dp_ln2g = need_plain(m, "dp.ln2.g", DF, miss); m->dp_ln2b = need_plain(m, "dp.ln2.b", DF, miss);
+  m->dp_proj_w = need_plain(m, "dp.proj.w", DF, miss); m->dp_proj_b = need_plain(m, "dp.proj.b", 1, miss);
+  m->pitch_proj_w = need_plain(m, "pitch.proj.w", C, miss); m->pitch_proj_b = need_plain(m, "pitch.proj.b", 1, miss);
+  m->pitch_pre_w = need_plain(m, "pitch_prenet.w", (int64_t)C * 3, miss); m->pitch_pre_b = need_plain(m, "pitch_prenet.b", C, miss);
+  m->en_conv1 = need_conv(m, "energy.conv1", C, EF, 3, MODE_PLAIN, miss);
+  m->en_conv2 = need_conv(m, "energy.conv2", EF, EF, 3, MODE_PLAIN, miss);
+  m->en_ln1g = need_plain(m, "energy.ln1.g", EF, miss); m->en_ln1b = need_plain(m, "energy.ln1.b", EF, miss);
+  m->en_ln2g = need_plain(m, "energy.ln2.g", EF, miss); m->en_ln2b = need_plain(m, "energy.ln2.b", EF, miss);
+  m->en_lin_w = need_plain(m, "energy.lin.w", EF, miss); m->en_lin_b = need_plain(m, "energy.lin.b", 1, miss);
+  m->en_pre_w = need_plain(m, "energy_prenet.w", (int64_t)C * 3, miss); m->en_pre_b = need_plain(m, "energy_prenet.b", C, miss);
+  m->project = need_conv(m, "project", C, 2 * C, 1, MODE_PLAIN, miss);
+  m->flows.clear();
+  for (int f = 0; f < c.n_flows; ++f) {
+    const std::string p = "flow." + std::to_string(f);
+    FlowLayer fl;
+    fl.pre = need_conv(m, p + ".pre", half, C, 1, MODE_PLAIN, miss);
+    fl.post = need_conv(m, p + ".post", C, half, 1, MODE_PLAIN, miss);
+    for (int l = 0; l < c.flow_layers; ++l) {
+      fl.in.push_back(need_conv(m, p + ".in." + std::to_string(l), C, 2 * C, c.flow_kernel, MODE_GATE, miss));
+      if (l + 1 < c.flow_layers) fl.res.push_back(need_conv(m, p + ".res." + std::to_string(l), C, C, 1, MODE_PLAIN, miss));
+      fl.skip.push_back(need_conv(m, p + ".skip." + std::to_string(l), C, C, 1, MODE_PLAIN, miss));
+    }
+    m->flows.push_back(fl);
+  }
+  m->conv_pre = need_conv(m, "dec.conv_pre", c.inter_channels, ch0, 7, MODE_PLAIN, miss);
+  m->ups.clear();
+  m->rbs.clear();
+  m->total_up = 1;
+  for (int i = 0; i < c.n_upsamples; ++i) {
+    const int u = c.upsample_rates[i], cin = ch0 >> i, cout = ch0 >> (i + 1);
+    const int mode = u == 8 ? MODE_UP8 : u == 4 ? MODE_UP4 : MODE_UP2;
+    m->ups.push_back(need_conv(m, "dec.ups." + std::to_string(i), cin, cout * u, c.upsample_kernel_sizes[i] / u, mode, miss));
+    m->total_up *= u;
+    for (int j = 0; j < c.n_resblock_kernels; ++j) {
+      ResBlock rb;
+      const std::string p = "dec.rb." + std::to_string(i * c.n_resblock_kernels + j);
+      for (int q = 0; q < c.n_resblock_dilations; ++q) {
+        rb.c1.push_back(need_conv(m, p + ".c1." + std::to_string(q), cout, cout, c.resblock_kernel_sizes[j], MODE_PLAIN, miss));
+        rb.c2.push_back(need_conv(m, p + ".c2." + std::to_string(q), cout, cout, c.resblock_kernel_sizes[j], MODE_PLAIN, miss));
+      }
+      m->rbs.push_back(rb);
+    }
+  }
+  m->conv_post_w = need_plain(m, "dec.conv_post.w", (int64_t)(ch0 >> c.n_upsamples) * 7, miss);
+  if (!miss.empty()) return fail(VITS_ERR_MISSING, "model is missing " + miss);
+  m->finalized = true;
+  return VITS_OK;
+}
+
+int vits_pack_conv_weight(const float* w, int rows, int cin, int taps, float* out) {
+  if (!w || !out || rows <= 0 || rows % 32 || cin <= 0 || cin % CI_CHUNK || taps < 1)
+    return fail(VITS_ERR_INVALID, "pack: rows % 32 == 0 and cin % 16 == 0 required");
+  const int mt_total = rows / 32, nchunks = cin / CI_CHUNK;
+  int64_t o = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk)
+    for (int k = 0; k < taps; ++k)
+      for (int sq = 0; sq < 2; ++sq)
+        for (int mt = 0; mt < mt_total; ++mt)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 4; ++e) {
+              const int row = mt * 32 + (lane & 31);
+              const int ci = chunk * CI_CHUNK + sq * 8 + e * 2 + (lane >> 5);
+              out[o++] = w[((int64_t)row * cin + ci) * taps + k];
+            }
+  return VITS_OK;
+}
+
+#define CHECK_MODEL(m)                                                             \
+  if (!(m) || !(m)->finalized) return fail(VITS_ERR_INVALID, "model not finalized")
+
+int vits_cond_rows(const vits_model* m) { return m && m->finalized ? m->cond_rows : -1; }
+
+int vits_speaker_cond(const vits_model* m, const int64_t* sid, int B, float* cond, int* err_flag, void* stream) {
+  CHECK_MODEL(m);
+  HIP_TRY(launch_cond_gemv(m->emb_g, sid, m->cond_w, m->cond_b, cond, B, m->cond_rows, m->cfg.gin_channels,
+                           m->cfg.n_speakers, err_flag, (hipStream_t)stream));
+  return VITS_OK;
+}
+
+int64_t vits_encoder_workspace_bytes(const vits_model* m, int B, int L) {
+  if (!m) return -1;
+  return encoder_ws_floats(m, B, L) * 4;
+}
+
+int vits_text_encoder(const vits_model* m, const int64_t* phonemes, const int* lengths, int B, int P, float* x,
+                      int* err_flag, void* ws, int64_t ws_bytes, void* stream) {
+  CHECK_MODEL(m);
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(launch_embed(phonemes, m->symbol_emb, lengths, x, B, P, m->cfg.hidden_channels, m->cfg.n_vocab, err_flag, s));
+  Arena ar(ws, ws_bytes);
+  return run_encoder(m, 0, x, lengths, B, P, ar, s);
+}
+
+int vits_encoder_stack(const vits_model* m, int which, float* x, const int* lengths, int B, int L, void* ws,
+                       int64_t ws_bytes, void* stream) {
+  CHECK_MODEL(m);
+  if (which < 0 || which > 2) return fail(VITS_ERR_INVALID, "encoder index must be 0, 1 or 2");
+  Arena ar(ws, ws_bytes);
+  return run_encoder(m, which, x, lengths, B, L, ar, (hipStream_t)stream);
+}
+
+int64_t vits_variance_workspace_bytes(const vits_model* m, int B, int P) {
+  if (!m) return -1;
+  const int64_t C = m->cfg.hidden_channels, EF = m->cfg.energy_filter, DF = m->cfg.dur_filter;
+  const int64_t big = std::max<int64_t>(std::max<int64_t>(EF, DF), C);
+  return 2 * pad256((int64_t)B * big * P) + 6 * pad256((int64_t)B * P) + encoder_ws_floats(m, B, P) * 4;
+}
+
+int vits_variance_adaptor(const vits_model* m, float* x, const int* lengths, const float* cond, int B, int P,
+                          int dur_mode, float dur_scale, float* dur_out, int pitch_mode, float pitch_scale,
+                          const float* pitch_hz, float* f0_out, int energy_mode, float energy_scale,
+                          const float* energy_raw, float* energy_out, void* ws, int64_t ws_bytes, void* stream) {
+  CHECK_MODEL(m);
+  hipStream_t s = (hipStream_t)stream;
+  const int C = m->cfg.hidden_channels, EF = m->cfg.energy_filter, DF = m->cfg.dur_filter;
+  const int big = std::max(std::max(EF, DF), C);
+  const int cr = m->cond_rows;
+  Arena ar(ws, ws_bytes);
+  float* h1 = ar.take((int64_t)B * big * P);
+  float* h2 = ar.take((int64_t)B * big * P);
+  float* v0 = ar.take((int64_t)B * P);   // logw / predictor outputs
+  float* lf0 = ar.take((int64_t)B * P);
+  float* ne = ar.take((int64_t)B * P);
+  if (!h1 || !h2 || !v0 || !lf0 || !ne) return fail(VITS_ERR_WORKSPACE, "variance adaptor: workspace too small");
+  // duration (reference models.py:125-139, 729-733)
+  if (dur_mode == 0) {
+    if (!dur_out) return fail(VITS_ERR_INVALID, "dur_out is required when durations are predicted");
+    TRY(conv_simple(m->dp_conv1, x, h1, B, P, lengths, F_IN_MASK | F_RELU, s, nullptr, nullptr, 0, cond + m->off_dp, cr));
+    HIP_TRY(launch_layer_norm(h1, h1, m->dp_ln1g, m->dp_ln1b, lengths, B, DF, P, false, s));
+    TRY(conv_simple(m->dp_conv2, h1, h2, B, P, lengths, F_IN_MASK | F_RELU, s));
+    HIP_TRY(launch_layer_norm(h2, h2, m->dp_ln2g, m->dp_ln2b, lengths, B, DF, P, false, s));
+    HIP_TRY(launch_conv_to1(h2, (long long)DF * P, P, m->dp_proj_w, m->dp_proj_b, v0, lengths, B, DF, 1, P, F_IN_MASK,
+                            1.f, 1.f, false, true, s));
+    HIP_TRY(launch_duration_finalize(v0, lengths, dur_scale, dur_out, B, P, s));
+  }
+  // pitch (reference models.py:547-556, 736-743)
+  if (pitch_mode == 0) {
+    HIP_TRY(launch_add_cbias_mask(x, cond + m->off_pitch, cr, lengths, h1, B, C, P, true, s));
+    TRY(run_encoder(m, 1, h1, lengths, B, P, ar, s));
+    HIP_TRY(launch_conv_to1(h1, (long long)C * P, P, m->pitch_proj_w, m->pitch_proj_b, v0, lengths, B, C, 1, P, 0, 1.f,
+                            1.f, false, false, s));
+    HIP_TRY(launch_pitch_math(v0, false, pitch_scale, lf0, f0_out, B * P, s));
+  } else {
+    if (!pitch_hz) return fail(VITS_ERR_INVALID, "pitch_hz is required for a pitch override");
+    HIP_TRY(launch_pitch_math(pitch_hz, true, 1.f, lf0, f0_out, B * P, s));
+  }
+  HIP_TRY(launch_prenet_add(x, lf0, m->pitch_pre_w, m->pitch_pre_b, B, C, P, s));
+  // energy (reference frame_prior_network.py:104-129, models.py:746-753): no masking anywhere
+  if (energy_mode == 0) {
+    TRY(conv_simple(m->en_conv1, x, h1, B, P, nullptr, F_RELU, s, nullptr, nullptr, 0, cond + m->off_energy, cr));
+    HIP_TRY(launch_layer_norm(h1, h1, m->en_ln1g, m->en_ln1b, nullptr, B, EF, P, false, s));
+    TRY(conv_simple(m->en_conv2, h1, h2, B, P, nullptr, F_RELU, s));
+    HIP_TRY(launch_layer_norm(h2, h2, m->en_ln2g, m->en_ln2b, nullptr, B, EF, P, false, s));
+    HIP_TRY(launch_conv_to1(h2, (long long)EF * P, P, m->en_lin_w, m->en_lin_b, v0, nullptr, B, EF, 1, P, 0, 1.f, 1.f,
+                            false, false, s));
+    HIP_TRY(launch_energy_math(v0, false, energy_scale, ne, energy_out, B * P, s));
+  } else {
+    if (!energy_raw) return fail(VITS_ERR_INVALID, "energy_raw is required for an energy override");
+    HIP_TRY(launch_energy_math(energy_raw, true, 1.f, ne, energy_out, B * P, s));
+  }
+  HIP_TRY(launch_prenet_add(x, ne, m->en_pre_w, m->en_pre_b, B, C, P, s));
+  return VITS_OK;
+}
+
+int vits_length_regulate_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, void* stream) {
+  if (!dur || !cum || !totals) return fail(VITS_ERR_INVALID, "length_regulate_plan: null argument");
+  if (P > 2048) return fail(VITS_ERR_INVALID, "length regulator supports at most 2048 phonemes per utterance");
+  HIP_TRY(launch_lr_plan(dur, dur_dtype, B, P, cum, totals, (hipStream_t)stream));
+  return VITS_OK;
+}
+
+int vits_length_regulate(const float* x, const int* cum, const int* totals, int B, int C, int P, int T, float* x_frame,
+                         void* stream) {
+  if (!x || !cum || !totals || !x_frame) return fail(VITS_ERR_INVALID, "length_regulate: null argument");
+  HIP_TRY(launch_lr_gather(x, cum, totals, x_frame, B, C, P, T, (hipStream_t)stream));
+  return VITS_OK;
+}
+
+int vits_frame_prior(const vits_model* m, float* x_frame, const int* frame_lengths, int B, int T, const float* noise,
+                     float noise_scale, float* stats, float* z_p, float* z, void* ws, int64_t ws_bytes, void* stream) {
+  CHECK_MODEL(m);
+  hipStream_t s = (hipStream_t)stream;
+  if (T > 2048) return fail(VITS_ERR_INVALID, "attention kernel supports at most 2048 frames per utterance");
+  Arena ar(ws, ws_bytes);
+  TRY(run_encoder(m, 2, x_frame, frame_lengths, B, T, ar, s));
+  TRY(conv_simple(m->project, x_frame, stats, B, T, frame_lengths, F_MASK_PRE, s));
+  HIP_TRY(launch_sample(stats, noise, noise_scale, z_p, z, B, m->cfg.inter_channels, T, s));
+  return VITS_OK;
+}
+
+int64_t vits_flow_workspace_bytes(const vits_model* m, int B, int T) {
+  if (!m) return -1;
+  return 3 * pad256((int64_t)B * m->cfg.hidden_channels * T);
+}
+
+int vits_flow_reverse(const vits_model* m, float* z, const int* lengths, const float* cond, int B, int T, void* ws,
+                      int64_t ws_bytes, void* stream) {
+  CHECK_MODEL(m);
+  hipStream_t s = (hipStream_t)stream;
+  const int C = m->cfg.hidden_channels, IC = m->cfg.inter_channels, half = IC / 2, NL = m->cfg.flow_layers;
+  const int cr = m->cond_rows, nf = m->cfg.n_flows;
+  Arena ar(ws, ws_bytes);
+  float* h = ar.take((int64_t)B * C * T);
+  float* acts = ar.take((int64_t)B * C * T);
+  float* skip = ar.take((int64_t)B * C * T);
+  if (!h || !acts || !skip) return fail(VITS_ERR_WORKSPACE, "flow: workspace too small");
+  for (int f = nf - 1; f >= 0; --f) {
+    // The reference flips all channels before every coupling layer (models.py:214-215, modules.py:266-273).  Here z
+    // stays in place: after an odd number of flips the layer reads the upper half as x0 and rewrites the lower half,
+    // and the channel reversal inside each half is folded into pre's input order and post's output order at load.
+    const bool flipped = (nf - f) & 1;
+    float* x0 = z + (flipped ? (long long)half * T : 0);
+    float* x1 = z + (flipped ? 0 : (long long)half * T);
+    const FlowLayer& fl = m->flows[f];
+    {
+      ConvArgs a = base_args(x0, (long long)IC * T, T, h, (long long)C * T, T, B, T, lengths, F_MASK_PRE);
+      HIP_TRY(launch_conv(fl.pre, a, s));
+    }
+    const float* cf = cond + m->off_flow + (long long)f * 2 * C * NL;
+    for (int l = 0; l < NL; ++l) {
+      TRY(conv_simple(fl.in[l], h, acts, B, T, lengths, 0, s, nullptr, cf + (long long)l * 2 * C, cr));
+      if (l + 1 < NL) {
+        TRY(conv_simple(fl.res[l], acts, h, B, T, lengths, F_RES | F_MASK_POST, s, h));
+        TRY(conv_simple(fl.skip[l], acts, skip, B, T, lengths, l ? F_ACCUM : 0, s));
+      } else {
+        TRY(conv_simple(fl.skip[l], acts, skip, B, T, lengths, (l ? F_ACCUM : 0) | F_MASK_POST, s));
+      }
+    }
+    {
+      ConvArgs a = base_args(skip, (long long)C * T, T, x1, (long long)IC * T, T, B, T, lengths,
+                             F_MASK_PRE | F_RES_SUB | F_MASK_POST);
+      a.res = x1; a.res_bs = (long long)IC * T; a.res_cs = T;
+      HIP_TRY(launch_conv(fl.post, a, s));
+    }
+  }
+  return VITS_OK;
+}
+
+static int64_t gen_buf_floats(const vits_model* m, int B, int t_dec) {
+  int64_t mx = (int64_t)m->cfg.upsample_initial_channel * t_dec;
+  int64_t L = t_dec;
+  for (int i = 0; i < m->cfg.n_upsamples; ++i) {
+    L *= m->cfg.upsample_rates[i];
+    mx = std::max<int64_t>(mx, (int64_t)(m->cfg.upsample_initial_channel >> (i + 1)) * L);
+  }
+  return mx * B;
+}
+
+int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec) {
+  if (!m) return -1;
+  return 4 * pad256(gen_buf_floats(m, B, t_dec));
+}
+
+int vits_generator(const vits_model* m, const float* z, const int* lengths, const float* cond, int B, int T, int t_dec,
+                   float* wav, void* ws, int64_t ws_bytes, void* stream) {
+  CHECK_MODEL(m);
+  hipStream_t s = (hipStream_t)stream;
+  if (t_dec <= 0 || t_dec > T) return fail(VITS_ERR_INVALID, "generator: 0 < t_dec <= T required");
+  const vits_config& c = m->cfg;
+  const int IC = c.inter_channels, ch0 = c.upsample_initial_channel, nk = c.n_resblock_kernels, nd = c.n_resblock_dilations;
+  Arena ar(ws, ws_bytes);
+  const int64_t nbuf = gen_buf_floats(m, B, t_dec);
+  float* buf[4];
+  for (auto& b : buf) {
+    b = ar.take(nbuf);
+    if (!b) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
+  }
+  float *X = buf[0], *Y = buf[1], *Tt = buf[2], *XS = buf[3];
+  // conv_pre on (z * mask)[:, :, :t_dec] + cond(g)   (reference models.py:285-287, 765)
+  {
+    ConvArgs a = base_args(z, (long long)IC * T, T, XS, (long long)ch0 * t_dec, t_dec, B, t_dec, lengths, F_IN_MASK);
+    a.cbias = cond + m->off_dec; a.cbias_bs = m->cond_rows;
+    HIP_TRY(launch_conv(m->conv_pre, a, s));
+  }
+  float in_scale = 1.f;
+  int L = t_dec;
+  for (int i = 0; i < c.n_upsamples; ++i) {
+    const int ch = ch0 >> (i + 1);
+    // x = ups[i](leaky_relu(x, 0.1)); the division by num_kernels of the previous stage rides on the input scale
+    TRY(conv_simple(m->ups[i], XS, X, B, L, nullptr, F_IN_LRELU, s, nullptr, nullptr, 0, nullptr, 0, in_scale, 0.1f));
+    L *= c.upsample_rates[i];
+    for (int j = 0; j < nk; ++j) {
+      const ResBlock& rb = m->rbs[i * nk + j];
+      const float* yin = X;
+      for (int q = 0; q < nd; ++q) {
+        TRY(conv_simple(rb.c1[q], yin, Tt, B, L, nullptr, F_IN_LRELU, s, nullptr, nullptr, 0, nullptr, 0, 1.f, 0.1f));
+        const bool last = q + 1 == nd;
+        float* dst = last ? XS : Y;
+        const int flags = F_IN_LRELU | F_RES | (last && j > 0 ? F_ACCUM : 0);
+        TRY(conv_simple(rb.c2[q], Tt, dst, B, L, nullptr, flags, s, yin, nullptr, 0, nullptr, 0, 1.f, 0.1f));
+        yin = Y;
+      }
+    }
+    in_scale = 1.f / (float)nk;
+    (void)ch;
+  }
+  // tanh(conv_post(leaky_relu(x, 0.01)))   (reference models.py:299-301)
+  HIP_TRY(launch_conv_to1(XS, (long long)(ch0 >> c.n_upsamples) * L, L, m->conv_post_w, nullptr, wav, nullptr, B,
+                          ch0 >> c.n_upsamples, 7, L, F_IN_LRELU, in_scale, 0.01f, true, false, s));
+  return VITS_OK;
+}
+
+// ---- single operators ----
+int vits_op_conv1d(const float* w, const float* bias, int cin, int rows, int taps, int dilation, int mode, const float* x,
+                   int B, int L, const int* lengths, const float* cbias, const float* in_cbias, const float* res,
+                   float* out, int flags, float in_scale, float in_slope, void* stream) {
+  ConvDesc d;
+  TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode));
+  return conv_simple(d, x, out, B, L, lengths, flags, (hipStream_t)stream, res, cbias, rows, in_cbias, cin, in_scale,
+                     in_slope);
+}
+
+int vits_op_layer_norm(const float* x, float* y, const float* gamma, const float* beta, const int* lengths, int B, int C,
+                       int L, int mask_out, void* stream) {
+  HIP_TRY(launch_layer_norm(x, y, gamma, beta, lengths, B, C, L, mask_out != 0, (hipStream_t)stream));
+  return VITS_OK;
+}
+
+int vits_op_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out, int B,
+                      int H, int DK, int L, int window, void* stream) {
+  HIP_TRY(launch_attention(qkv, emb_k, emb_v, lengths, out, B, H, DK, L, window, (hipStream_t)stream));
+  return VITS_OK;
+}
+
+}  // extern "C"

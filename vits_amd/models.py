@@ -1,0 +1,283 @@
+"""Drop-in for the reference's ``models.SynthesizerTrn`` inference surface on MI355X.
+
+Construction arguments, ``load_state_dict`` / checkpoint layout, the ``infer`` signature, its 6-tuple return and its
+error behaviour follow reference models.py:577-767.  All arithmetic runs in libvits_amd.so (hand-written HIP
+kernels, include/vits_amd.h); PyTorch is used here only to own device memory, to provide the current HIP stream and
+to draw the prior noise when the caller does not pass one.  There is no fallback: without the library or without a
+GPU this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+
+from . import _native as N
+from . import synthetic, weights
+
+_DUR_DTYPES = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.float64: 3}
+
+
+class SynthesizerTrn:
+    """Inference-only synthesizer (the training nets of the reference, enc_q and the discriminators, are not built)."""
+
+    def __init__(self, n_vocab, spec_channels, hop_length, sampling_rate, segment_size, inter_channels,
+                 hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, resblock,
+                 resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates, upsample_initial_channel,
+                 upsample_kernel_sizes, n_speakers=0, gin_channels=0, use_sdp=False, freeze_textencoder=False,
+                 freeze_decoder=False, **kwargs):
+        if str(resblock) != "1":
+            raise NotImplementedError("only resblock='1' (ResBlock1) is implemented; the reference config uses it")
+        if n_speakers <= 1 or gin_channels <= 0:
+            raise NotImplementedError("a speaker-conditioned model (n_speakers > 1, gin_channels > 0) is required")
+        self.cfg = synthetic.ModelConfig(
+            n_vocab=n_vocab, spec_channels=spec_channels, hop_length=hop_length, sampling_rate=sampling_rate,
+            segment_size=segment_size, inter_channels=inter_channels, hidden_channels=hidden_channels,
+            filter_channels=filter_channels, n_heads=n_heads, n_layers=n_layers, kernel_size=kernel_size,
+            p_dropout=p_dropout, resblock=str(resblock), resblock_kernel_sizes=tuple(resblock_kernel_sizes),
+            resblock_dilation_sizes=tuple(tuple(d) for d in resblock_dilation_sizes),
+            upsample_rates=tuple(upsample_rates), upsample_initial_channel=upsample_initial_channel,
+            upsample_kernel_sizes=tuple(upsample_kernel_sizes), n_speakers=n_speakers, gin_channels=gin_channels)
+        self.n_vocab, self.n_speakers, self.gin_channels = n_vocab, n_speakers, gin_channels
+        self.hidden_channels, self.inter_channels = hidden_channels, inter_channels
+        self.hop_length, self.sampling_rate = hop_length, sampling_rate
+        self.total_upsample = 1
+        for u in upsample_rates:
+            self.total_upsample *= u
+        self._manifest = synthetic.state_dict_manifest(self.cfg)
+        self._sd: Dict[str, torch.Tensor] = {}
+        self._handle = C.c_void_p()
+        self._device_tensors = []           # keeps packed weights alive for the library
+        self._ws: Optional[torch.Tensor] = None
+        self._ready = False
+        self.device = torch.device("cuda", 0)
+        c = N.VitsConfig()
+        cfg = self.cfg
+        c.n_vocab, c.hidden_channels, c.inter_channels = cfg.n_vocab, cfg.hidden_channels, cfg.inter_channels
+        c.filter_channels, c.n_heads, c.n_layers, c.kernel_size = cfg.filter_channels, cfg.n_heads, cfg.n_layers, cfg.kernel_size
+        c.gin_channels, c.n_speakers = cfg.gin_channels, cfg.n_speakers
+        c.pitch_layers, c.dur_filter, c.energy_filter = cfg.pitch_layers, cfg.dur_filter, cfg.energy_filter
+        c.n_flows, c.flow_layers, c.flow_kernel, c.window_size = cfg.n_flows, cfg.flow_layers, cfg.flow_kernel, cfg.window_size
+        c.n_upsamples = len(cfg.upsample_rates)
+        for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+            c.upsample_rates[i], c.upsample_kernel_sizes[i] = u, k
+        c.upsample_initial_channel = cfg.upsample_initial_channel
+        c.n_resblock_kernels = len(cfg.resblock_kernel_sizes)
+        for j, k in enumerate(cfg.resblock_kernel_sizes):
+            c.resblock_kernel_sizes[j] = k
+        nd = {len(d) for d in cfg.resblock_dilation_sizes}
+        if len(nd) != 1:
+            raise NotImplementedError("every resblock must have the same number of dilations")
+        c.n_resblock_dilations = nd.pop()
+        for j, dl in enumerate(cfg.resblock_dilation_sizes):
+            for q, d in enumerate(dl):
+                c.resblock_dilation_sizes[j][q] = d
+        N.check(N.lib.vits_model_create(C.byref(c), C.byref(self._handle)), "vits_model_create")
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            N.lib.vits_model_destroy(h)
+            self._handle = C.c_void_p()
+
+    # ---- torch.nn.Module look-alikes used by the reference's callers (inference.py:23-42) ----
+    def eval(self):
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("vits_amd.SynthesizerTrn is inference-only")
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("vits_amd runs on an MI355X only; there is no CPU path")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device != self.device:
+            self.device = device
+            if self._sd:
+                self._upload()
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", 0 if device is None else device))
+
+    def state_dict(self):
+        """Every checkpoint key with the tensor currently held, or a shape-only (meta) tensor when none is."""
+        return OrderedDict((k, self._sd.get(k, torch.empty(shp, device="meta"))) for k, shp in self._manifest.items())
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts the reference's generator state dict.  Keys infer never reads (enc_q.*, enc_p.proj.*, ...) are
+        optional; any other absent key is an error, because an uninitialised weight cannot produce meaningful audio."""
+        sd = {}
+        for k, v in state_dict.items():
+            if isinstance(v, torch.Tensor) and v.device.type != "meta":
+                if k in self._manifest and tuple(v.shape) != tuple(self._manifest[k]):
+                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)}, model {tuple(self._manifest[k])}")
+                sd[k] = v.detach().to("cpu", torch.float32)
+        needed = [k for k in self._manifest if not k.startswith(weights.UNUSED_PREFIXES)]
+        missing = [k for k in needed if k not in sd]
+        if missing:
+            raise RuntimeError(f"state dict is missing {len(missing)} tensors the synthesis path needs, e.g. {missing[:4]}")
+        if strict:
+            unexpected = [k for k in sd if k not in self._manifest]
+            if unexpected:
+                raise RuntimeError(f"unexpected keys in state dict: {unexpected[:4]}")
+        self._sd = sd
+        self._upload()
+        return self
+
+    def _upload(self):
+        if not torch.cuda.is_available():
+            raise RuntimeError("vits_amd needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
+        pw = weights.prepare(self._sd, self.cfg)
+        self._device_tensors = []
+        h = self._handle
+        with torch.cuda.device(self.device):
+            for name, t in pw.plain.items():
+                d = t.to(self.device)
+                self._device_tensors.append(d)
+                N.check(N.lib.vits_model_set_tensor(h, name.encode(), d.data_ptr(), d.numel()), f"set_tensor {name}")
+            for name, (w, b, cin, rows, taps, dil, mode) in pw.convs.items():
+                dw = w.to(self.device)
+                db = None if b is None else b.to(self.device)
+                self._device_tensors += [dw, db]
+                N.check(N.lib.vits_model_set_conv(h, name.encode(), dw.data_ptr(), N.ptr(db), cin, rows, taps, dil, mode),
+                        f"set_conv {name}")
+            N.check(N.lib.vits_model_finalize(h), "vits_model_finalize")
+            torch.cuda.synchronize(self.device)
+        self._ready = True
+
+    # ---- workspace ----
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != self.device:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ---- the hot path ----
+    @torch.no_grad()
+    def infer(self, phonemes, phonemes_lengths, sid=None, noise_scale=1, max_len=None, energy_control=None,
+              pitch_control=None, duration_control=None, noise=None, stages: Optional[dict] = None):
+        """reference models.py:717-767.  Extra keyword ``noise`` ([B, inter_channels, T]) replaces the
+        torch.randn_like draw at :763; ``stages`` (a dict) receives stage-boundary tensors for tests."""
+        if not self._ready:
+            raise RuntimeError("no weights loaded: call load_state_dict / utils.load_checkpoint first")
+        if sid is None:
+            # the reference calls self.emb_g(None) here and dies with a TypeError (models.py:719-720)
+            raise TypeError("sid is required: the model is speaker-conditioned (n_speakers > 0)")
+        lib, h, dev = N.lib, self._handle, self.device
+        cfg = self.cfg
+        Cc, IC = cfg.hidden_channels, cfg.inter_channels
+        if phonemes.dim() != 2:
+            raise ValueError("phonemes must be [B, P]")
+        B, P = phonemes.shape
+        f32 = dict(dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            ph = phonemes.to(dev, torch.int64).contiguous()
+            lens = phonemes_lengths.to(dev, torch.int32).contiguous()
+            sids = sid.to(dev, torch.int64).contiguous().reshape(-1)
+            if lens.numel() != B or sids.numel() != B:
+                raise ValueError("phonemes_lengths and sid must have one entry per batch row")
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            cond = torch.empty(B, lib.vits_cond_rows(h), **f32)
+            N.check(lib.vits_speaker_cond(h, sids.data_ptr(), B, cond.data_ptr(), err.data_ptr(), stream), "speaker_cond")
+            # text encoder
+            x = torch.empty(B, Cc, P, **f32)
+            ws_bytes = max(lib.vits_encoder_workspace_bytes(h, B, P), lib.vits_variance_workspace_bytes(h, B, P))
+            ws = self._workspace(ws_bytes)
+            N.check(lib.vits_text_encoder(h, ph.data_ptr(), lens.data_ptr(), B, P, x.data_ptr(), err.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), stream), "text_encoder")
+            if stages is not None:
+                stages["enc_p"] = x.clone()
+            # variance adaptor
+            dur_is_tensor = isinstance(duration_control, torch.Tensor)
+            pitch_is_tensor = isinstance(pitch_control, torch.Tensor)
+            energy_is_tensor = isinstance(energy_control, torch.Tensor)
+            dur_scale = 1.0 if duration_control is None or dur_is_tensor else float(duration_control)
+            pitch_scale = 1.0 if pitch_control is None or pitch_is_tensor else float(pitch_control)
+            energy_scale = 1.0 if energy_control is None or energy_is_tensor else float(energy_control)
+            dur_pred = None if dur_is_tensor else torch.empty(B, 1, P, **f32)
+            f0 = torch.empty(B, P, **f32)
+            energy = torch.empty(B, P, **f32)
+            pitch_in = energy_in = None
+            if pitch_is_tensor:
+                pitch_in = pitch_control.to(dev, torch.float32).contiguous()
+                if tuple(pitch_in.shape) != (B, P):
+                    raise ValueError("pitch_control tensor must be [B, P] (Hz per phoneme)")
+            if energy_is_tensor:
+                energy_in = energy_control.to(dev, torch.float32).contiguous()
+                if tuple(energy_in.shape) != (B, P):
+                    raise ValueError("energy_control tensor must be [B, P]")
+            N.check(lib.vits_variance_adaptor(
+                h, x.data_ptr(), lens.data_ptr(), cond.data_ptr(), B, P,
+                1 if dur_is_tensor else 0, dur_scale, N.ptr(dur_pred),
+                1 if pitch_is_tensor else 0, pitch_scale, N.ptr(pitch_in), f0.data_ptr(),
+                1 if energy_is_tensor else 0, energy_scale, N.ptr(energy_in), energy.data_ptr(),
+                ws.data_ptr(), ws.numel(), stream), "variance_adaptor")
+            if stages is not None:
+                stages["x_phone"] = x.clone()
+            # length regulator: plan on device, one small D2H copy to size the frame tensors
+            if dur_is_tensor:
+                duration = duration_control
+                d = duration_control
+                if d.dtype not in _DUR_DTYPES:
+                    d = d.to(torch.float32 if d.is_floating_point() else torch.int64)
+                d = d.to(dev).contiguous()
+                if d.numel() != B * P:
+                    raise ValueError("duration_control tensor must hold one value per phoneme ([B, P] or [B, 1, P])")
+            else:
+                duration = dur_pred
+                d = dur_pred
+            cum = torch.empty(B, P, dtype=torch.int32, device=dev)
+            totals = torch.empty(B, dtype=torch.int32, device=dev)
+            N.check(lib.vits_length_regulate_plan(d.data_ptr(), _DUR_DTYPES[d.dtype], B, P, cum.data_ptr(),
+                                                  totals.data_ptr(), stream), "length_regulate_plan")
+            host = torch.cat([totals, err]).cpu()          # synchronises the stream
+            if int(host[-1]) & 1:
+                raise IndexError("phoneme id out of range of the symbol table")
+            if int(host[-1]) & 2:
+                raise IndexError("speaker id out of range")
+            T = int(host[:-1].max())
+            if T <= 0:
+                raise ValueError("all durations are zero: nothing to synthesise")
+            x_frame = torch.empty(B, Cc, T, **f32)
+            N.check(lib.vits_length_regulate(x.data_ptr(), cum.data_ptr(), totals.data_ptr(), B, Cc, P, T,
+                                             x_frame.data_ptr(), stream), "length_regulate")
+            if stages is not None:
+                stages["x_frame"] = x_frame.clone()
+                stages["x_lengths"] = totals.to(torch.int64)
+            # frame prior, projection, sampling
+            if noise is None:
+                noise_t = torch.randn(B, IC, T, **f32)
+            else:
+                noise_t = noise.to(dev, torch.float32).contiguous()
+                if tuple(noise_t.shape) != (B, IC, T):
+                    raise ValueError(f"noise must be [{B}, {IC}, {T}]")
+            t_dec = len(range(T)[:max_len])
+            if t_dec <= 0:
+                raise ValueError("max_len leaves no frames to decode")
+            need = max(lib.vits_encoder_workspace_bytes(h, B, T), lib.vits_flow_workspace_bytes(h, B, T),
+                       lib.vits_generator_workspace_bytes(h, B, t_dec))
+            ws = self._workspace(need)
+            stats = torch.empty(B, 2 * IC, T, **f32)
+            z_p = torch.empty(B, IC, T, **f32)
+            z = torch.empty(B, IC, T, **f32)
+            N.check(lib.vits_frame_prior(h, x_frame.data_ptr(), totals.data_ptr(), B, T, noise_t.data_ptr(),
+                                         float(noise_scale), stats.data_ptr(), z_p.data_ptr(), z.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), stream), "frame_prior")
+            if stages is not None:
+                stages["prior"] = x_frame.clone()
+            N.check(lib.vits_flow_reverse(h, z.data_ptr(), totals.data_ptr(), cond.data_ptr(), B, T, ws.data_ptr(),
+                                          ws.numel(), stream), "flow_reverse")
+            o = torch.empty(B, 1, t_dec * self.total_upsample, **f32)
+            N.check(lib.vits_generator(h, z.data_ptr(), totals.data_ptr(), cond.data_ptr(), B, T, t_dec, o.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), stream), "generator")
+            x_mask = (torch.arange(T, device=dev)[None, :] < totals[:, None]).unsqueeze(1)
+            m_p, logs_p = stats[:, :IC], stats[:, IC:]
+        return o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy
