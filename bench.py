@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the MVTS synthesis path (SynthesizerTrn.infer) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step is one infer call over one batch of synthetic utterances whose inputs are already resident in HBM.  The
+workload is BASELINE.json's configs[1]: 16 utterances of 50 phonemes / 258 frames (3.0 s of 44.1 kHz audio each),
+fp32, fixed MFA-style durations, fixed noise; every rank runs its own batch (utterance-level data parallelism, no
+collective on the data path, weak scaling).  Rank 0 prints one JSON line:
+  value      = audio-seconds synthesised per wall-second, summed over ranks (max-over-ranks time)
+  roofline   = the dominant kernel (the fp32 MFMA conv) timed with HIP events on its launch stream
+  cpu_baseline = the CPU oracle (a PyTorch fp32 port of the reference's infer) timed on this host's cores on a
+                 bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (256 CUs x 256 FLOP/clk x 2.4 GHz)
+
+
+def build_model(device):
+    from vits_amd import SynthesizerTrn, synthetic
+    cfg = synthetic.ModelConfig()
+    net = SynthesizerTrn(cfg.n_vocab, cfg.spec_channels, cfg.hop_length, cfg.sampling_rate, cfg.segment_size,
+                         **cfg.kwargs()).eval()
+    net.to(device)
+    net.load_state_dict(synthetic.synthetic_state_dict(cfg, include_enc_q=False), strict=True)
+    return net
+
+
+def to_device(batch, device):
+    return dict(phonemes=batch.phonemes.to(device), lengths=batch.lengths.to(device), sid=batch.sid.to(device),
+                durations=batch.durations.to(device), noise=batch.noise.to(device))
+
+
+def step(net, d, noise_scale=0.667):
+    return net.infer(d["phonemes"], d["lengths"], sid=d["sid"], noise_scale=noise_scale,
+                     duration_control=d["durations"], noise=d["noise"])[0]
+
+
+def algorithmic_flops(phoneme_counts, frame_counts, predicted_duration=False):
+    """2*MAC per utterance, banded relative attention, weight-norm folded (duration predictor only when it runs)."""
+    per_p = 25757696 - (0 if predicted_duration else 688640)
+    return sum(837861376 * t + 3072 * t * t + per_p * p + 7680 * p * p for p, t in zip(phoneme_counts, frame_counts))
+
+
+def cpu_baseline(sample_utts=4, runs=2):
+    """Time the CPU oracle on a bounded sample: `sample_utts` utterances of the benchmark workload."""
+    from oracle.mvts_oracle import OracleSynthesizer
+    from vits_amd import synthetic
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    sd = synthetic.synthetic_state_dict(include_enc_q=False)
+    orc = OracleSynthesizer(sd)
+    b = synthetic.make_batch(1, [50] * sample_utts, [258] * sample_utts)
+    kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
+    orc.infer(b.phonemes[:1], b.lengths[:1], sid=b.sid[:1], noise_scale=b.noise_scale,
+              duration_control=b.durations[:1], noise=b.noise[:1])           # warm-up
+    best = float("inf")
+    out = None
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        out = orc.infer(b.phonemes, b.lengths, **kw)[0]
+        best = min(best, time.perf_counter() - t0)
+    return dict(value=round(b.audio_seconds / best, 3), unit="audio-s/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{sample_utts} utterances x 258 frames (3.0 s each) of the benchmark batch, fp32, "
+                       f"best of {runs} runs after warm-up; PyTorch CPU oracle (oracle/mvts_oracle.py)"), out, b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from vits_amd import _native as N
+    from vits_amd import synthetic
+    net = build_model(device)
+    # every rank synthesises its own utterances: same shapes, different ids / durations / speakers / noise
+    batch = synthetic.make_batch(1 + rank, [50] * args.batch, [258] * args.batch)
+    d = to_device(batch, device)
+    audio_s = batch.audio_seconds
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step(net, d)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(net, d)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # dominant kernel: per-launch HIP-event timing over `steps` more steps of the same workload
+        N.lib.vits_profile_reset()
+        N.lib.vits_profile_enable(1)
+        for _ in range(args.steps):
+            step(net, d)
+        torch.cuda.synchronize(device)
+        N.lib.vits_profile_enable(0)
+        rows = sorted(N.profile_rows(), key=lambda r: -r["ms"])
+        dom = rows[0]
+        conv_ms = sum(r["ms"] for r in rows)
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        launches_per_step=dom["count"] // args.steps,
+                        avg_launch_us=round(dom["ms"] * 1e3 / dom["count"], 2),
+                        flops_per_launch=round(dom["flops"] / dom["count"]),
+                        share_of_conv_time=round(dom["ms"] / conv_ms, 3),
+                        all_conv_kernels=[dict(kernel=r["name"], tflops=round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                                               ms_per_step=round(r["ms"] / args.steps, 3),
+                                               launches_per_step=r["count"] // args.steps) for r in rows])
+        # batch-1 latency (3.0 s utterance)
+        b1 = to_device(synthetic.config_c1(), device)
+        for _ in range(3):
+            step(net, b1)
+        torch.cuda.synchronize(device)
+        lat = []
+        for _ in range(20):
+            t1 = time.perf_counter()
+            step(net, b1)
+            torch.cuda.synchronize(device)
+            lat.append(time.perf_counter() - t1)
+        lat.sort()
+        rtf = lat[len(lat) // 2] / synthetic.config_c1().audio_seconds
+        flops_step = algorithmic_flops([50] * args.batch, [258] * args.batch)
+        result = {
+            "metric": "audio-sec/sec at 44.1 kHz",
+            "value": round(world * args.steps * audio_s / elapsed, 2),
+            "unit": "audio-s/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"C2: batch {args.batch} x 50 phonemes x 258 frames (3.0 s each), fixed durations, "
+                                   "fixed noise, fp32; one batch per GPU per step",
+                       "batch_per_gpu": args.batch, "frames": 258, "parallelism": f"utterance-dp{world}"},
+            "whole_path_tflops": round(world * args.steps * flops_step / elapsed / 1e12, 2),
+            "rtf_batch1": round(rtf, 5),
+            "batch1_latency_ms": round(lat[len(lat) // 2] * 1e3, 3),
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            cb, cpu_out, cpu_batch = cpu_baseline()
+            # the same sample through the GPU path: keeps the two numbers about the same work, and checks parity
+            dd = to_device(cpu_batch, device)
+            gpu_out = step(net, dd).cpu()
+            cb["gpu_vs_oracle_max_abs"] = float((gpu_out - cpu_out).abs().max())
+            result["cpu_baseline"] = cb
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

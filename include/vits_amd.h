@@ -112,6 +112,14 @@ int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec);
 int vits_generator(const vits_model* m, const float* z, const int* frame_lengths, const float* cond, int B, int T,
                    int t_dec, float* wav, void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- per-kernel timing of the conv launches (HIP events on the launch stream; off by default).  No counterpart
+ * in the reference.  vits_profile_read(-1, ...) resolves pending events (synchronises) and returns the number of
+ * rows; vits_profile_read(i, ...) returns row i: kernel instantiation name, summed algorithmic FLOPs
+ * (2 * rows * cin * taps * L * B per launch), summed milliseconds and launch count since the last reset. */
+void vits_profile_enable(int on);
+void vits_profile_reset(void);
+int vits_profile_read(int index, char* name, int name_len, double* flops, double* ms, int64_t* count);
+
 /* ---- single operators, exposed for unit parity tests ---- */
 int vits_op_conv1d(const float* packed_w, const float* bias_rows, int cin, int rows, int taps, int dilation, int mode,
                    const float* x, int B, int L, const int* lengths, const float* cbias, const float* in_cbias,

@@ -6,6 +6,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must be imported before the library is opened: both link libamdhip64.so.7, and the process must end up with
+# ONE HIP runtime -- the one PyTorch ships -- or device pointers and streams could not be shared between the two.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvits_amd.so")
 
@@ -60,6 +64,10 @@ def _load():
         "vits_flow_reverse": (i32, [vp, vp, vp, vp, i32, i32, vp, i64, vp]),
         "vits_generator_workspace_bytes": (i64, [vp, i32, i32]),
         "vits_generator": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp]),
+        "vits_profile_enable": (None, [i32]),
+        "vits_profile_reset": (None, []),
+        "vits_profile_read": (i32, [i32, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int64)]),
         "vits_op_conv1d": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, f32, f32, vp]),
         "vits_op_layer_norm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "vits_op_attention": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -85,3 +93,15 @@ def check(rc: int, what: str = "") -> None:
 def ptr(t) -> int:
     """Device (or host) address of a torch tensor / None."""
     return 0 if t is None else t.data_ptr()
+
+
+def profile_rows():
+    """Resolve and return the per-kernel timing rows: list of dict(name, flops, ms, count)."""
+    n = lib.vits_profile_read(-1, None, 0, None, None, None)
+    rows = []
+    for i in range(n):
+        name = C.create_string_buffer(128)
+        fl, ms, cnt = C.c_double(), C.c_double(), C.c_int64()
+        check(lib.vits_profile_read(i, name, 128, C.byref(fl), C.byref(ms), C.byref(cnt)), "profile_read")
+        rows.append(dict(name=name.value.decode(), flops=fl.value, ms=ms.value, count=cnt.value))
+    return rows

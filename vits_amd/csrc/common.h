@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
+#include <vector>
 
 namespace vits {
 
@@ -60,6 +62,16 @@ struct ConvArgs {
 };
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
+
+// Optional per-kernel timing of the conv launches with HIP events on the launch stream (off by default).
+struct ProfRow {
+  std::string name;      // kernel instantiation, e.g. conv_mfma_kernel<2,2,1,4,0> = <WM,WN,WGM,WGN,MODE>
+  double flops, ms;      // algorithmic FLOPs (2*rows*cin*taps*L*B) and summed event time
+  long long count;
+};
+void prof_enable(bool on);
+void prof_reset();
+int prof_collect(std::vector<ProfRow>& rows);
 
 // ---------------------------------------------------------------------------------------------------------
 // other kernels (kernels_misc.hip)

@@ -15,7 +15,70 @@
 //   C/D: column = time = lane & 31, so every accumulator register stores 128 contiguous bytes per half wave.
 #include "common.h"
 
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 namespace vits {
+
+// ---- optional per-kernel timing (HIP events on the launch stream), off by default ----
+namespace {
+struct ProfClass {
+  double flops = 0.0, ms = 0.0;
+  long long count = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::map<std::string, ProfClass> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t prof_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+void prof_enable(bool on) { g_prof_on = on; }
+
+void prof_reset() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& kv : g_prof) {
+    for (auto& p : kv.second.pending) {
+      g_event_pool.push_back(p.first);
+      g_event_pool.push_back(p.second);
+    }
+  }
+  g_prof.clear();
+}
+
+// Resolves pending events (synchronises on them) and returns the number of classes.
+int prof_collect(std::vector<ProfRow>& rows) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  rows.clear();
+  for (auto& kv : g_prof) {
+    ProfClass& c = kv.second;
+    for (auto& p : c.pending) {
+      float ms = 0.f;
+      (void)hipEventSynchronize(p.second);
+      (void)hipEventElapsedTime(&ms, p.first, p.second);
+      c.ms += ms;
+      g_event_pool.push_back(p.first);
+      g_event_pool.push_back(p.second);
+    }
+    c.pending.clear();
+    rows.push_back(ProfRow{kv.first, c.flops, c.ms, c.count});
+  }
+  return (int)rows.size();
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -264,8 +327,30 @@ static hipError_t launch_cfg(ConvArgs& a, hipStream_t stream) {
   const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + WM - 1) / WM;
   dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
   const size_t lds = (size_t)CI_CHUNK * a.rs * sizeof(float);
+  if (!g_prof_on) {
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+  }
+  char name[96];
+  snprintf(name, sizeof name, "conv_mfma_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
+  hipEvent_t e0, e1;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    e0 = prof_event();
+    e1 = prof_event();
+  }
+  (void)hipEventRecord(e0, stream);
   hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
-  return hipGetLastError();
+  hipError_t err = hipGetLastError();
+  (void)hipEventRecord(e1, stream);
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfClass& c = g_prof[name];
+    c.flops += 2.0 * a.M * a.Cin * a.K * (double)a.L * a.B;     // algorithmic: dense over every position
+    c.count += 1;
+    c.pending.emplace_back(e0, e1);
+  }
+  return err;
 }
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {

@@ -605,6 +605,21 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
   return VITS_OK;
 }
 
+// ---- per-kernel timing ----
+void vits_profile_enable(int on) { prof_enable(on != 0); }
+void vits_profile_reset(void) { prof_reset(); }
+
+int vits_profile_read(int index, char* name, int name_len, double* flops, double* ms, int64_t* count) {
+  static thread_local std::vector<ProfRow> rows;
+  if (index < 0) return prof_collect(rows);
+  if (index >= (int)rows.size() || !name || name_len <= 0) return fail(VITS_ERR_INVALID, "profile_read: bad index");
+  snprintf(name, name_len, "%s", rows[index].name.c_str());
+  if (flops) *flops = rows[index].flops;
+  if (ms) *ms = rows[index].ms;
+  if (count) *count = rows[index].count;
+  return VITS_OK;
+}
+
 // ---- single operators ----
 int vits_op_conv1d(const float* w, const float* bias, int cin, int rows, int taps, int dilation, int mode, const float* x,
                    int B, int L, const int* lengths, const float* cbias, const float* in_cbias, const float* res,
