@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency section (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,17 +147,19 @@ def main():
                                                ms_per_step=round(r["ms"] / args.steps, 3),
                                                launches_per_step=r["count"] // args.steps) for r in rows])
         # batch-1 latency (3.0 s utterance)
-        b1 = to_device(synthetic.config_c1(), device)
-        for _ in range(3):
-            step(net, b1)
-        torch.cuda.synchronize(device)
-        lat = []
-        for _ in range(20):
-            t1 = time.perf_counter()
-            step(net, b1)
+        lat = [float("nan")]
+        if not args.no_latency:
+            b1 = to_device(synthetic.config_c1(), device)
+            for _ in range(3):
+                step(net, b1)
             torch.cuda.synchronize(device)
-            lat.append(time.perf_counter() - t1)
-        lat.sort()
+            lat = []
+            for _ in range(20):
+                t1 = time.perf_counter()
+                step(net, b1)
+                torch.cuda.synchronize(device)
+                lat.append(time.perf_counter() - t1)
+            lat.sort()
         rtf = lat[len(lat) // 2] / synthetic.config_c1().audio_seconds
         flops_step = algorithmic_flops([50] * args.batch, [258] * args.batch)
         result = {
@@ -176,8 +179,8 @@ def main():
                                    "fixed noise, fp32; one batch per GPU per step",
                        "batch_per_gpu": args.batch, "frames": 258, "parallelism": f"utterance-dp{world}"},
             "whole_path_tflops": round(world * args.steps * flops_step / elapsed / 1e12, 2),
-            "rtf_batch1": round(rtf, 5),
-            "batch1_latency_ms": round(lat[len(lat) // 2] * 1e3, 3),
+            "rtf_batch1": None if args.no_latency else round(rtf, 5),
+            "batch1_latency_ms": None if args.no_latency else round(lat[len(lat) // 2] * 1e3, 3),
             "roofline": roofline,
         }
         if not args.no_cpu_baseline:
