@@ -82,10 +82,12 @@ int prof_collect(std::vector<ProfRow>& rows) {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM, int WN, int WGM, int WGN, int MODE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+// VEC = true: the input rows are 16-byte aligned and L % 4 == 0, so activations are staged with dwordx4 loads and
+// ds_write_b128 (a group of four time steps is then entirely inside or entirely outside [0, L)).
+template <int WM, int WN, int WGM, int WGN, int MODE, bool VEC>
+__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int BN = 32 * WN * WGN;
-  constexpr int NCOLS = (BN + MAX_HALO + 63) / 64;
+  constexpr int NCOLS = VEC ? (BN + MAX_HALO + 4 + 255) / 256 : (BN + MAX_HALO + 63) / 64;
   constexpr bool TWO_CLASS = (MODE == MODE_UP8 || MODE == MODE_UP2);
   constexpr int NB = TWO_CLASS ? 2 : 1;
   static_assert(WGM * WGN == 4, "four waves per block");
@@ -93,7 +95,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   static_assert(MODE != MODE_GATE || WM == 2, "gate pairs the tanh and sigmoid rows in one wave");
 
   extern __shared__ __attribute__((aligned(16))) float xs[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: tile indices stay scalar
   const int wm = wave / WGN, wn = wave % WGN;
   const int par = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z;
@@ -118,19 +121,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
 
-  // ---- activation staging (global -> registers -> LDS) ----
+  // ---- activation staging (global -> registers -> LDS), input prologue applied on the way ----
+  // LDS column c of the tile holds time step tstart + c.  VEC: tstart is rounded down to a multiple of 4.
   const float* xb = a.x + (long long)b * a.x_bs;
-  const int tstart = t0 + a.min_off;
-  float st[4][NCOLS];
+  const int tfirst = t0 + a.min_off;
+  const int tstart = VEC ? (tfirst & ~3) : tfirst;
+  const int lead = tfirst - tstart;                       // 0 when !VEC
+  const int wcols = a.width + lead;                       // columns to stage
+  auto prologue = [&](float v, float cb, int t) -> float {
+    v = (v + cb) * a.in_scale;
+    if (a.flags & F_IN_LRELU) v = fmaxf(v, v * a.in_slope);       // leaky relu, 0 <= slope <= 1
+    if (a.flags & F_IN_MASK) v = t < len_b ? v : 0.f;
+    return v;
+  };
+  float st[4][NCOLS][VEC ? 4 : 1];
   auto load_chunk = [&](int chunk) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float* xr = xb + (long long)(chunk * CI_CHUNK + wave * 4 + r) * a.x_cs;
 #pragma unroll
       for (int q = 0; q < NCOLS; ++q) {
-        const int col = lane + 64 * q, t = tstart + col;
-        const bool ok = col < a.width && t >= 0 && t < a.L;
-        st[r][q] = ok ? xr[t] : 0.f;
+        if constexpr (VEC) {
+          const int col = 4 * (lane + 64 * q), t = tstart + col;
+          const bool ok = col < wcols && t >= 0 && t < a.L;
+          // clamped address + select instead of a branch around the load
+          const float4 v = *reinterpret_cast<const float4*>(xr + (ok ? t : 0));
+          st[r][q][0] = ok ? v.x : 0.f;
+          st[r][q][1] = ok ? v.y : 0.f;
+          st[r][q][2] = ok ? v.z : 0.f;
+          st[r][q][3] = ok ? v.w : 0.f;
+        } else {
+          const int col = lane + 64 * q, t = tstart + col;
+          const bool ok = col < wcols && t >= 0 && t < a.L;
+          const float v = xr[ok ? t : 0];
+          st[r][q][0] = ok ? v : 0.f;
+        }
       }
     }
   };
@@ -141,12 +166,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       const float cb = a.in_cbias ? a.in_cbias[(long long)b * a.in_cbias_bs + chunk * CI_CHUNK + row] : 0.f;
 #pragma unroll
       for (int q = 0; q < NCOLS; ++q) {
-        const int col = lane + 64 * q, t = tstart + col;
-        float v = (st[r][q] + cb) * a.in_scale;
-        if (a.flags & F_IN_LRELU) v = v > 0.f ? v : v * a.in_slope;
-        bool ok = t >= 0 && t < a.L;
-        if (a.flags & F_IN_MASK) ok = ok && t < len_b;
-        if (col < a.width) xs[row * rs + col] = ok ? v : 0.f;
+        if constexpr (VEC) {
+          const int col = 4 * (lane + 64 * q), t = tstart + col;
+          const bool ok = t >= 0 && t < a.L;              // zero padding stays zero (not prologue(0))
+          float4 v;
+          v.x = ok ? prologue(st[r][q][0], cb, t) : 0.f;
+          v.y = ok ? prologue(st[r][q][1], cb, t + 1) : 0.f;
+          v.z = ok ? prologue(st[r][q][2], cb, t + 2) : 0.f;
+          v.w = ok ? prologue(st[r][q][3], cb, t + 3) : 0.f;
+          if (col < wcols) *reinterpret_cast<float4*>(&xs[row * rs + col]) = v;
+        } else {
+          const int col = lane + 64 * q, t = tstart + col;
+          const bool ok = t >= 0 && t < a.L;
+          if (col < wcols) xs[row * rs + col] = ok ? prologue(st[r][q][0], cb, t) : 0.f;
+        }
       }
     }
   };
@@ -196,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       }
   };
 
-  const int colbase = wn * WN * 32 + l31 + par * rs - a.min_off;
+  const int colbase = wn * WN * 32 + l31 + par * rs - a.min_off + lead;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     if (chunk + 1 < nchunks) load_chunk(chunk + 1);
     int boff[NB];
@@ -225,6 +258,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   }
 
   // ---- epilogue ----
+  // Addresses are a wave-uniform row base (scalar registers) plus ONE per-lane element offset shared by all rows.
+  // All loads of a tile are issued before its first store: out may alias res (in-place residual update), so a
+  // per-element load -> store sequence would serialise 16 memory round trips.
   const float* cbias_b = a.cbias ? a.cbias + (long long)b * a.cbias_bs : nullptr;
   float* out_b = a.out + (long long)b * a.out_bs;
   if constexpr (MODE == MODE_PLAIN) {
@@ -232,44 +268,69 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       if (!mt_ok[i]) continue;
+      const int rowu = mt[i] * 32;
+      float bz[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowu + 4 * par + (r & 3) + 8 * (r >> 2);
+        bz[r] = a.bias ? a.bias[row] : 0.f;
+        if (cbias_b) bz[r] += cbias_b[row];
+      }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int t = t0 + (wn * WN + j) * 32 + l31;
-        if (t >= a.L) continue;
-        const float m = t < len_b ? 1.f : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = mt[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * par;
-          float v = acc[i][j][r];
-          if (a.bias) v += a.bias[row];
-          if (cbias_b) v += cbias_b[row];
-          if (a.flags & F_RELU) v = fmaxf(v, 0.f);
-          if (a.flags & F_MASK_PRE) v *= m;
+        if (t < a.L) {
+          const float m = t < len_b ? 1.f : 0.f;
+          const unsigned lo_out = (unsigned)(4 * par * a.out_cs + t);
+          const unsigned lo_res = (unsigned)(4 * par * a.res_cs + t);
+          float rv[16], ov[16];
           if (a.flags & (F_RES | F_RES_SUB)) {
-            const float rv = res_b[(long long)row * a.res_cs + t];
-            v = (a.flags & F_RES_SUB) ? rv - v : v + rv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              rv[r] = (res_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.res_cs)[lo_res];
           }
-          float* op = out_b + (long long)row * a.out_cs + t;
-          if (a.flags & F_ACCUM) v += *op;
-          if (a.flags & F_MASK_POST) v *= m;
-          *op = v;
+          if (a.flags & F_ACCUM) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              ov[r] = (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r] + bz[r];
+            if (a.flags & F_RELU) v = fmaxf(v, 0.f);
+            if (a.flags & F_MASK_PRE) v *= m;
+            if (a.flags & F_RES) v += rv[r];
+            if (a.flags & F_RES_SUB) v = rv[r] - v;
+            if (a.flags & F_ACCUM) v += ov[r];
+            if (a.flags & F_MASK_POST) v *= m;
+            (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = v;
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);   // one tile's loads in flight at a time: bounds the register count
       }
     }
   } else if constexpr (MODE == MODE_GATE) {
     if (mt_ok[0]) {
       const int hrows = a.M >> 1;
+      const int rowu = mt[0] * 32;
+      float ba[16], bs[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowu + (r & 3) + 8 * (r >> 2) + 4 * par;
+        ba[r] = a.bias ? a.bias[row] : 0.f;
+        bs[r] = a.bias ? a.bias[row + hrows] : 0.f;
+        if (cbias_b) { ba[r] += cbias_b[row]; bs[r] += cbias_b[row + hrows]; }
+      }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int t = t0 + (wn * WN + j) * 32 + l31;
         if (t >= a.L) continue;
+        const unsigned lo_out = (unsigned)(4 * par * a.out_cs + t);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = mt[0] * 32 + (r & 3) + 8 * (r >> 2) + 4 * par;
-          float va = acc[0][j][r], vs = acc[WM - 1][j][r];
-          if (a.bias) { va += a.bias[row]; vs += a.bias[row + hrows]; }
-          if (cbias_b) { va += cbias_b[row]; vs += cbias_b[row + hrows]; }
-          out_b[(long long)row * a.out_cs + t] = tanhf(va) * (1.f / (1.f + expf(-vs)));
+          const float va = acc[0][j][r] + ba[r], vs = acc[WM - 1][j][r] + bs[r];
+          (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] =
+              tanhf(va) * (1.f / (1.f + expf(-vs)));
         }
       }
     }
@@ -281,20 +342,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       if (!mt_ok[i]) continue;
       const int cb = MODE == MODE_UP8 ? (mt[i] >> 1) : mt[i];
       const int ph0 = MODE == MODE_UP8 ? 4 * (mt[i] & 1) : 0;
+      float bz[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bz[g] = a.bias ? a.bias[mt[i] * 32 + 8 * g + 4 * par] : 0.f;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int t = t0 + (wn * WN + j) * 32 + l31;
         if (t >= a.L) continue;
+        const unsigned lo_out = (unsigned)(par * a.out_cs + UP * t + ph0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int co = cb * 8 + 2 * g + par;
-          const float bz = a.bias ? a.bias[mt[i] * 32 + 8 * g + 4 * par] : 0.f;
           float4 v;
-          v.x = acc[i][j][4 * g + 0] + bz;
-          v.y = acc[i][j][4 * g + 1] + bz;
-          v.z = acc[i][j][4 * g + 2] + bz;
-          v.w = acc[i][j][4 * g + 3] + bz;
-          *reinterpret_cast<float4*>(out_b + (long long)co * a.out_cs + (long long)UP * t + ph0) = v;
+          v.x = acc[i][j][4 * g + 0] + bz[g];
+          v.y = acc[i][j][4 * g + 1] + bz[g];
+          v.z = acc[i][j][4 * g + 2] + bz[g];
+          v.w = acc[i][j][4 * g + 3] + bz[g];
+          *reinterpret_cast<float4*>(out_b + (long long)(cb * 8 + 2 * g) * a.out_cs + lo_out) = v;
         }
       }
     }
@@ -303,36 +366,36 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     for (int i = 0; i < WM; ++i) {
       if (!mt_ok[i]) continue;
       const int cb = mt[i] >> 1, ph = mt[i] & 1;
+      float bz[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bz[r] = a.bias ? a.bias[mt[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * par] : 0.f;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int t = t0 + (wn * WN + j) * 32 + l31;
         if (t >= a.L) continue;
+        const unsigned lo_out = (unsigned)(4 * par * a.out_cs + 2 * t + ph);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = (r & 3) + 8 * (r >> 2) + 4 * par;
-          float v = acc[i][j][r];
-          if (a.bias) v += a.bias[mt[i] * 32 + rl];
-          out_b[(long long)(cb * 32 + rl) * a.out_cs + 2LL * t + ph] = v;
-        }
+        for (int r = 0; r < 16; ++r)
+          (out_b + (long long)(cb * 32 + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = acc[i][j][r] + bz[r];
       }
     }
   }
 }
 
-template <int WM, int WN, int WGM, int WGN, int MODE>
-static hipError_t launch_cfg(ConvArgs& a, hipStream_t stream) {
+template <int WM, int WN, int WGM, int WGN, int MODE, bool VEC>
+static hipError_t launch_one(ConvArgs& a, hipStream_t stream) {
   constexpr int BN = 32 * WN * WGN;
   a.width = BN + (a.width);          // caller passes halo span in a.width
-  a.rs = (a.width + 3) & ~3;
+  a.rs = (a.width + 3 + 3) & ~3;     // + up to 3 lead columns when the tile start is rounded down to a multiple of 4
   const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + WM - 1) / WM;
   dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
   const size_t lds = (size_t)CI_CHUNK * a.rs * sizeof(float);
   if (!g_prof_on) {
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE, VEC>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
   }
   char name[96];
-  snprintf(name, sizeof name, "conv_mfma_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
+  snprintf(name, sizeof name, "conv_mfma_kernel<%d,%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE, (int)VEC);
   hipEvent_t e0, e1;
   {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -340,7 +403,7 @@ static hipError_t launch_cfg(ConvArgs& a, hipStream_t stream) {
     e1 = prof_event();
   }
   (void)hipEventRecord(e0, stream);
-  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE, VEC>), grid, dim3(256), lds, stream, a);
   hipError_t err = hipGetLastError();
   (void)hipEventRecord(e1, stream);
   {
@@ -351,6 +414,14 @@ static hipError_t launch_cfg(ConvArgs& a, hipStream_t stream) {
     c.pending.emplace_back(e0, e1);
   }
   return err;
+}
+
+template <int WM, int WN, int WGM, int WGN, int MODE>
+static hipError_t launch_cfg(ConvArgs& a, hipStream_t stream) {
+  // dwordx4 staging needs 16-byte aligned rows and whole groups of four time steps
+  const bool vec = a.L % 4 == 0 && a.x_cs % 4 == 0 && a.x_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+  if (vec) return launch_one<WM, WN, WGM, WGN, MODE, true>(a, stream);
+  return launch_one<WM, WN, WGM, WGN, MODE, false>(a, stream);
 }
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
