@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -446,6 +447,9 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
     case MODE_PLAIN:
       if (M % 64 == 0) {
         if (L <= 96 && M % 128 == 0) return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, stream);
+        // taller block tiles when there are enough rows: one staged activation tile then feeds 128 / 256 rows
+        if (M % 256 == 0) return launch_cfg<2, 2, 4, 1, MODE_PLAIN>(a, stream);
+        if (M % 128 == 0) return launch_cfg<2, 2, 2, 2, MODE_PLAIN>(a, stream);
         return launch_cfg<2, 2, 1, 4, MODE_PLAIN>(a, stream);
       }
       if (L > 1024) return launch_cfg<1, 4, 1, 4, MODE_PLAIN>(a, stream);

@@ -5,7 +5,9 @@
 #include "../../include/vits_amd.h"
 
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -68,6 +70,11 @@ struct vits_model {
   const float* conv_post_w = nullptr;
   int cond_rows = 0, off_dp = 0, off_pitch = 0, off_energy = 0, off_dec = 0, off_flow = 0;
   int total_up = 1;
+  // side streams + events so that the generator's independent ResBlock chains can overlap (one chain's
+  // memory-bound phases run under another chain's MFMA phases); created at finalize on the then-current device
+  hipStream_t side[8] = {};
+  hipEvent_t ev_fork = nullptr, ev_done[8] = {};
+  int n_side = 0;
 };
 
 namespace {
@@ -248,7 +255,22 @@ int vits_model_create(const vits_config* cfg, vits_model** out) {
   return VITS_OK;
 }
 
-void vits_model_destroy(vits_model* m) { delete m; }
+static void release_streams(vits_model* m) {
+  for (int i = 0; i < m->n_side; ++i) (void)hipStreamDestroy(m->side[i]);
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  for (auto& e : m->ev_done) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+  m->ev_fork = nullptr;
+  m->n_side = 0;
+}
+
+void vits_model_destroy(vits_model* m) {
+  if (!m) return;
+  release_streams(m);
+  delete m;
+}
 
 int vits_model_set_tensor(vits_model* m, const char* name, const float* p, int64_t numel) {
   if (!m || !name || !p || numel <= 0) return fail(VITS_ERR_INVALID, "set_tensor: bad argument");
@@ -348,6 +370,16 @@ int vits_model_finalize(vits_model* m) {
   }
   m->conv_post_w = need_plain(m, "dec.conv_post.w", (int64_t)(ch0 >> c.n_upsamples) * 7, miss);
   if (!miss.empty()) return fail(VITS_ERR_MISSING, "model is missing " + miss);
+  release_streams(m);
+  const char* env = getenv("VITS_GEN_STREAMS");
+  const int want = env ? atoi(env) : c.n_resblock_kernels;
+  const int n_side = std::max(0, std::min(want, c.n_resblock_kernels) - 1);
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+  for (int i = 0; i < c.n_resblock_kernels; ++i) HIP_TRY(hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming));
+  for (int i = 0; i < n_side; ++i) {
+    HIP_TRY(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
+    m->n_side = i + 1;
+  }
   m->finalized = true;
   return VITS_OK;
 }
@@ -553,7 +585,7 @@ static int64_t gen_buf_floats(const vits_model* m, int B, int t_dec) {
 
 int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec) {
   if (!m) return -1;
-  return 4 * pad256(gen_buf_floats(m, B, t_dec));
+  return (2 + 2 * (int64_t)m->cfg.n_resblock_kernels) * pad256(gen_buf_floats(m, B, t_dec));
 }
 
 int vits_generator(const vits_model* m, const float* z, const int* lengths, const float* cond, int B, int T, int t_dec,
@@ -565,12 +597,13 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
   const int IC = c.inter_channels, ch0 = c.upsample_initial_channel, nk = c.n_resblock_kernels, nd = c.n_resblock_dilations;
   Arena ar(ws, ws_bytes);
   const int64_t nbuf = gen_buf_floats(m, B, t_dec);
-  float* buf[4];
-  for (auto& b : buf) {
-    b = ar.take(nbuf);
-    if (!b) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
+  float *X = ar.take(nbuf), *XS = ar.take(nbuf), *Y[8], *Tt[8];
+  for (int j = 0; j < nk; ++j) {
+    Y[j] = ar.take(nbuf);
+    Tt[j] = ar.take(nbuf);
+    if (!Y[j] || !Tt[j]) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
   }
-  float *X = buf[0], *Y = buf[1], *Tt = buf[2], *XS = buf[3];
+  if (!X || !XS) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
   // conv_pre on (z * mask)[:, :, :t_dec] + cond(g)   (reference models.py:285-287, 765)
   {
     ConvArgs a = base_args(z, (long long)IC * T, T, XS, (long long)ch0 * t_dec, t_dec, B, t_dec, lengths, F_IN_MASK);
@@ -580,24 +613,33 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
   float in_scale = 1.f;
   int L = t_dec;
   for (int i = 0; i < c.n_upsamples; ++i) {
-    const int ch = ch0 >> (i + 1);
     // x = ups[i](leaky_relu(x, 0.1)); the division by num_kernels of the previous stage rides on the input scale
     TRY(conv_simple(m->ups[i], XS, X, B, L, nullptr, F_IN_LRELU, s, nullptr, nullptr, 0, nullptr, 0, in_scale, 0.1f));
     L *= c.upsample_rates[i];
+    // The nk ResBlocks read the same x and are independent until their outputs are summed (models.py:292-298):
+    // chain j runs on its own stream; its last conv accumulates into XS after chain j-1's has (same order of
+    // additions as the reference: (rb0 + rb1) + rb2).
+    if (m->n_side > 0) {
+      HIP_TRY(hipEventRecord(m->ev_fork, s));
+      for (int j = 0; j < m->n_side; ++j) HIP_TRY(hipStreamWaitEvent(m->side[j], m->ev_fork, 0));
+    }
     for (int j = 0; j < nk; ++j) {
+      hipStream_t sj = (j == 0 || m->n_side == 0) ? s : m->side[std::min(j, m->n_side) - 1];
       const ResBlock& rb = m->rbs[i * nk + j];
       const float* yin = X;
       for (int q = 0; q < nd; ++q) {
-        TRY(conv_simple(rb.c1[q], yin, Tt, B, L, nullptr, F_IN_LRELU, s, nullptr, nullptr, 0, nullptr, 0, 1.f, 0.1f));
+        TRY(conv_simple(rb.c1[q], yin, Tt[j], B, L, nullptr, F_IN_LRELU, sj, nullptr, nullptr, 0, nullptr, 0, 1.f, 0.1f));
         const bool last = q + 1 == nd;
-        float* dst = last ? XS : Y;
+        float* dst = last ? XS : Y[j];
         const int flags = F_IN_LRELU | F_RES | (last && j > 0 ? F_ACCUM : 0);
-        TRY(conv_simple(rb.c2[q], Tt, dst, B, L, nullptr, flags, s, yin, nullptr, 0, nullptr, 0, 1.f, 0.1f));
-        yin = Y;
+        if (last && j > 0 && m->n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
+        TRY(conv_simple(rb.c2[q], Tt[j], dst, B, L, nullptr, flags, sj, yin, nullptr, 0, nullptr, 0, 1.f, 0.1f));
+        yin = Y[j];
       }
+      if (m->n_side > 0) HIP_TRY(hipEventRecord(m->ev_done[j], sj));
     }
+    if (m->n_side > 0) HIP_TRY(hipStreamWaitEvent(s, m->ev_done[nk - 1], 0));
     in_scale = 1.f / (float)nk;
-    (void)ch;
   }
   // tanh(conv_post(leaky_relu(x, 0.01)))   (reference models.py:299-301)
   HIP_TRY(launch_conv_to1(XS, (long long)(ch0 >> c.n_upsamples) * L, L, m->conv_post_w, nullptr, wav, nullptr, B,
