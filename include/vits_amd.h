@@ -50,17 +50,22 @@ void vits_model_destroy(vits_model* m);
 /* Register a plain fp32 tensor (bias, LayerNorm gain, embedding table ...) under `name`. The memory stays owned
  * by the caller and must outlive the model. */
 int vits_model_set_tensor(vits_model* m, const char* name, const float* dev_ptr, int64_t numel);
-/* Register a convolution whose weight was folded (weight-norm) and packed by vits_pack_conv_weight.
+/* Register a convolution whose weight was folded (weight-norm) and packed by vits_pack_conv_weight*.
  * mode: 0 plain, 1 gated (tanh*sigmoid halves), 2/3/4 transposed conv with stride 8/4/2.
+ * precision: 0 = fp32 MFMA on fp32-packed weights; 1 = three-term bf16 split ("bf16x3": both operands are split
+ *   exactly into three bf16 terms, six cross products on the bf16 MFMA, fp32 accumulate; fp32-grade results) on
+ *   weights packed by vits_pack_conv_weight_bf16x3.
  * rows = packed GEMM rows (cout, or cout*stride for a transposed conv); bias has `rows` entries or is NULL. */
-int vits_model_set_conv(vits_model* m, const char* name, const float* packed_w, const float* bias_rows, int cin,
-                        int rows, int taps, int dilation, int mode);
+int vits_model_set_conv(vits_model* m, const char* name, const void* packed_w, const float* bias_rows, int cin,
+                        int rows, int taps, int dilation, int mode, int precision);
 /* Resolve every name the synthesis path needs; fails with VITS_ERR_MISSING naming the first absent tensor. */
 int vits_model_finalize(vits_model* m);
 
 /* Host-side packing of one conv weight into MFMA fragment order.  host_w is the folded weight laid out as
  * [rows][cin][taps] (row order for transposed convs: see vits_amd/weights.py); host_out gets rows*cin*taps floats. */
 int vits_pack_conv_weight(const float* host_w, int rows, int cin, int taps, float* host_out);
+/* Same for the bf16x3 mode: host_out gets 3*rows*cin*taps uint16 (bf16 bit patterns). */
+int vits_pack_conv_weight_bf16x3(const float* host_w, int rows, int cin, int taps, uint16_t* host_out);
 
 /* ---- stages of SynthesizerTrn.infer ---- */
 
@@ -121,9 +126,10 @@ void vits_profile_reset(void);
 int vits_profile_read(int index, char* name, int name_len, double* flops, double* ms, int64_t* count);
 
 /* ---- single operators, exposed for unit parity tests ---- */
-int vits_op_conv1d(const float* packed_w, const float* bias_rows, int cin, int rows, int taps, int dilation, int mode,
-                   const float* x, int B, int L, const int* lengths, const float* cbias, const float* in_cbias,
-                   const float* res, float* out, int flags, float in_scale, float in_slope, void* stream);
+int vits_op_conv1d(const void* packed_w, const float* bias_rows, int cin, int rows, int taps, int dilation, int mode,
+                   int precision, const float* x, int B, int L, const int* lengths, const float* cbias,
+                   const float* in_cbias, const float* res, float* out, int flags, float in_scale, float in_slope,
+                   void* stream);
 int vits_op_layer_norm(const float* x, float* y, const float* gamma, const float* beta, const int* lengths, int B, int C,
                        int L, int mask_out, void* stream);
 int vits_op_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out, int B,

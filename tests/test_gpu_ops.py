@@ -22,18 +22,26 @@ def dev(t):
     return None if t is None else t.cuda().contiguous()
 
 
+PREC = {"fp32": 0, "bf16x3": 1}
+
+
+@pytest.fixture(params=["fp32", "bf16x3"])
+def prec(request):
+    return PREC[request.param]
+
+
 def gpu_conv(N, w, bias, x, dilation=1, mode=0, flags=0, lengths=None, cbias=None, in_cbias=None, res=None,
-             out_init=None, in_scale=1.0, in_slope=1.0, up=1, bias_rows=None):
+             out_init=None, in_scale=1.0, in_slope=1.0, up=1, bias_rows=None, prec=0):
     """w: logical [rows, cin, taps] (already in kernel row order for transposed convs)."""
     from vits_amd import weights
     rows, cin, taps = w.shape
     B, _, L = x.shape
     cout = rows // 2 if mode == N.MODE_GATE else rows // up
-    pk = dev(weights.pack_rows(w))
+    pk = dev(weights.pack_rows(w, prec))
     b = dev(bias_rows if bias_rows is not None else bias)
     xd, ld, cb, icb, rd = dev(x), dev(lengths), dev(cbias), dev(in_cbias), dev(res)
     out = dev(out_init) if out_init is not None else torch.full((B, cout, L * up), float("nan"), device="cuda")
-    N.check(N.lib.vits_op_conv1d(pk.data_ptr(), N.ptr(b), cin, rows, taps, dilation, mode, xd.data_ptr(), B, L,
+    N.check(N.lib.vits_op_conv1d(pk.data_ptr(), N.ptr(b), cin, rows, taps, dilation, mode, prec, xd.data_ptr(), B, L,
                                  N.ptr(ld), N.ptr(cb), N.ptr(icb), N.ptr(rd), out.data_ptr(), flags, in_scale,
                                  in_slope, torch.cuda.current_stream().cuda_stream), "op_conv1d")
     torch.cuda.synchronize()
@@ -56,18 +64,18 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("cout,cin,k,dil,B,L", CONV_CASES)
-def test_conv_plain(N, cout, cin, k, dil, B, L):
+def test_conv_plain(N, prec, cout, cin, k, dil, B, L):
     g = torch.Generator().manual_seed(cout * 131 + cin + k + L)
     w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
     b = torch.randn(cout, generator=g)
     x = torch.randn(B, cin, L, generator=g)
     ref = F.conv1d(x, w, b, padding=(k - 1) // 2 * dil, dilation=dil)
-    got = gpu_conv(N, w, b, x, dilation=dil)
+    got = gpu_conv(N, w, b, x, dilation=dil, prec=prec)
     assert got.shape == ref.shape
     assert (got - ref).abs().max() < 2e-5
 
 
-def test_conv_prologue_epilogue_flags(N):
+def test_conv_prologue_epilogue_flags(N, prec):
     g = torch.Generator().manual_seed(7)
     cout, cin, k, B, L = 64, 48, 3, 3, 333
     w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
@@ -85,16 +93,16 @@ def test_conv_prologue_epilogue_flags(N):
     ref = ((torch.relu(y) * m) + res + init) * m
     flags = N.F_IN_LRELU | N.F_IN_MASK | N.F_RELU | N.F_MASK_PRE | N.F_RES | N.F_ACCUM | N.F_MASK_POST
     got = gpu_conv(N, w, b, x, flags=flags, lengths=lengths, cbias=cbias, in_cbias=icb, res=res, out_init=init,
-                   in_scale=0.5, in_slope=0.1)
+                   in_scale=0.5, in_slope=0.1, prec=prec)
     assert (got - ref).abs().max() < 2e-5
     # res - y form used by the coupling layer
     ref2 = (res - (F.conv1d(x, w, b, padding=1) * m)) * m
-    got2 = gpu_conv(N, w, b, x, flags=N.F_MASK_PRE | N.F_RES_SUB | N.F_MASK_POST, lengths=lengths, res=res)
+    got2 = gpu_conv(N, w, b, x, flags=N.F_MASK_PRE | N.F_RES_SUB | N.F_MASK_POST, lengths=lengths, res=res, prec=prec)
     assert (got2 - ref2).abs().max() < 2e-5
 
 
 @pytest.mark.parametrize("L", [40, 258, 700])
-def test_conv_gate(N, L):
+def test_conv_gate(N, prec, L):
     g = torch.Generator().manual_seed(L)
     H, k, B = 192, 5, 2
     w = torch.randn(2 * H, H, k, generator=g) / math.sqrt(H * k)
@@ -103,13 +111,13 @@ def test_conv_gate(N, L):
     cb = torch.randn(B, 2 * H, generator=g)
     a = F.conv1d(x, w, b, padding=2) + cb[:, :, None]
     ref = torch.tanh(a[:, :H]) * torch.sigmoid(a[:, H:])
-    got = gpu_conv(N, w, b, x, mode=N.MODE_GATE, cbias=cb)
+    got = gpu_conv(N, w, b, x, mode=N.MODE_GATE, cbias=cb, prec=prec)
     assert (got - ref).abs().max() < 2e-5
 
 
 @pytest.mark.parametrize("u,k,cin,cout,L", [(8, 16, 512, 256, 258), (8, 16, 256, 128, 1500), (4, 4, 128, 64, 700),
                                             (2, 4, 64, 32, 1111), (8, 16, 32, 16, 3)])
-def test_conv_transpose(N, u, k, cin, cout, L):
+def test_conv_transpose(N, prec, u, k, cin, cout, L):
     from vits_amd import weights
     g = torch.Generator().manual_seed(u * 1000 + L)
     wt = torch.randn(cin, cout, k, generator=g) / math.sqrt(cin * k / u)
@@ -120,7 +128,7 @@ def test_conv_transpose(N, u, k, cin, cout, L):
     ref = F.conv_transpose1d(F.leaky_relu(x / 3, 0.1), wt, b, stride=u, padding=(k - u) // 2)
     w_rows, b_rows, mode, taps = weights.transposed_conv_rows(wt, b, u, k, (k - u) // 2)
     got = gpu_conv(N, w_rows, None, x, mode=mode, up=u, bias_rows=b_rows, flags=N.F_IN_LRELU, in_scale=1.0 / 3,
-                   in_slope=0.1)
+                   in_slope=0.1, prec=prec)
     assert got.shape == ref.shape
     assert (got - ref).abs().max() < 2e-5
 

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--frames", type=int, default=258)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--prec", default="bf16x3")
     a = ap.parse_args()
     B = a.batch
     stream = torch.cuda.current_stream().cuda_stream
@@ -43,7 +44,7 @@ def main():
             continue
         up = {N.MODE_UP8: 8, N.MODE_UP4: 4, N.MODE_UP2: 2}.get(mode, 1)
         w = torch.randn(rows, cin, taps) / math.sqrt(cin * taps)
-        pk = weights.pack_rows(w).cuda()
+        pk = weights.pack_rows(w, N.PRECISIONS[a.prec]).cuda()
         bias = torch.randn(rows).cuda()
         x = torch.randn(B, cin, L, device="cuda")
         res = torch.randn(B, rows // up, L, device="cuda") if mode == 0 else None
@@ -52,7 +53,8 @@ def main():
         flags |= int(os.environ.get("VITS_DBG_FLAGS", "0"))
 
         def run():
-            N.check(N.lib.vits_op_conv1d(pk.data_ptr(), bias.data_ptr(), cin, rows, taps, dil, mode, x.data_ptr(), B, L,
+            N.check(N.lib.vits_op_conv1d(pk.data_ptr(), bias.data_ptr(), cin, rows, taps, dil, mode, N.PRECISIONS[a.prec],
+                                         x.data_ptr(), B, L,
                                          0, 0, 0, N.ptr(res), out.data_ptr(), flags, 1.0, 0.1, stream))
         run()
         torch.cuda.synchronize()

@@ -46,9 +46,10 @@ def _load():
         "vits_model_create": (i32, [C.POINTER(VitsConfig), C.POINTER(vp)]),
         "vits_model_destroy": (None, [vp]),
         "vits_model_set_tensor": (i32, [vp, C.c_char_p, vp, i64]),
-        "vits_model_set_conv": (i32, [vp, C.c_char_p, vp, vp, i32, i32, i32, i32, i32]),
+        "vits_model_set_conv": (i32, [vp, C.c_char_p, vp, vp, i32, i32, i32, i32, i32, i32]),
         "vits_model_finalize": (i32, [vp]),
         "vits_pack_conv_weight": (i32, [vp, i32, i32, i32, vp]),
+        "vits_pack_conv_weight_bf16x3": (i32, [vp, i32, i32, i32, vp]),
         "vits_cond_rows": (i32, [vp]),
         "vits_speaker_cond": (i32, [vp, vp, i32, vp, vp, vp]),
         "vits_encoder_workspace_bytes": (i64, [vp, i32, i32]),
@@ -68,7 +69,7 @@ def _load():
         "vits_profile_reset": (None, []),
         "vits_profile_read": (i32, [i32, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int64)]),
-        "vits_op_conv1d": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, f32, f32, vp]),
+        "vits_op_conv1d": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, f32, f32, vp]),
         "vits_op_layer_norm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "vits_op_attention": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     }
@@ -82,6 +83,8 @@ def _load():
 lib, EXPORTED = _load()
 
 MODE_PLAIN, MODE_GATE, MODE_UP8, MODE_UP4, MODE_UP2 = 0, 1, 2, 3, 4
+PREC_F32, PREC_BF16X3 = 0, 1
+PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3}
 F_IN_LRELU, F_IN_MASK, F_RELU, F_MASK_PRE, F_RES, F_RES_SUB, F_ACCUM, F_MASK_POST = (1 << i for i in range(8))
 
 

@@ -18,6 +18,11 @@ enum ConvMode : int {
   MODE_UP2   = 4,   // transposed conv, stride 2, kernel 4,  padding 1
 };
 
+enum ConvPrec : int {
+  PREC_F32    = 0,   // v_mfma_f32_32x32x2_f32, packed fp32 weights
+  PREC_BF16X3 = 1,   // three-term bf16 split of both operands on v_mfma_f32_32x32x16_bf16 (fp32-grade results)
+};
+
 enum ConvFlags : int {
   F_IN_LRELU  = 1 << 0,   // leaky-relu(in_slope) on the input
   F_IN_MASK   = 1 << 1,   // input *= (t < len[b])
@@ -34,7 +39,8 @@ constexpr int MAX_TAPS = 12;
 constexpr int MAX_HALO = 64;    // max (max_off - min_off) a tile may need
 
 struct ConvDesc {          // one packed convolution, immutable after load
-  const float* w = nullptr;      // packed [Cin/16][K][2][M/32][64][4]
+  const void* w = nullptr;       // PREC_F32: fp32 [Cin/16][K][2][M/32][64][4]; PREC_BF16X3: bf16 [Cin/16][K][M/32][3][64][8]
+  int prec = PREC_F32;
   const float* bias = nullptr;   // [M] per-row bias, may be null
   int Cin = 0, M = 0, K = 0, mode = MODE_PLAIN;
   int toff0[2] = {0, 0};         // input time offset of tap k, per row class: toff0 + k * tstep
@@ -46,7 +52,7 @@ struct ConvDesc {          // one packed convolution, immutable after load
 
 struct ConvArgs {
   const float* x; long long x_bs; int x_cs;          // input [B][Cin][*], batch / channel strides in floats
-  const float* w; const float* bias;
+  const void* w; const float* bias;
   const float* cbias; int cbias_bs;                  // per-(batch,row) additive bias, or null
   const float* in_cbias; int in_cbias_bs;            // per-(batch,ci) additive input bias, or null
   float* out; long long out_bs; int out_cs;

@@ -1,18 +1,23 @@
-// fp32 MFMA implicit-GEMM convolution for gfx950 (v_mfma_f32_32x32x2_f32, wave64).
+// MFMA implicit-GEMM convolution for gfx950 (wave64).
 //
-// One kernel serves every conv1d / conv_transpose1d on the synthesis path (reference: nn.Conv1d uses in
+// One kernel family serves every conv1d / conv_transpose1d on the synthesis path (reference: nn.Conv1d uses in
 // attentions.py:196-199,373-374, models.py:116-120,263-283,543,567,657-658, modules.py:129-142,187-202,314-316,
 // frame_prior_network.py:39-47).
 //
 //   GEMM view:  D[row, t] = sum over (ci, tap) of  W[row, ci, tap] * X[ci, t + toff(tap)]
 //     M = rows (output channels; for a transposed conv: (channel, phase) pairs), N = time, K = Cin * taps.
-//   A operand (weights) comes pre-packed in exact fragment order, so each lane fetches one float4 per four
-//   k-steps straight from global memory (L2-resident, 1 KiB per wave instruction, no LDS round trip).
-//   B operand (activations) is staged per 16 input channels into an LDS tile [16][BN + halo] with the input
-//   prologue (scale, leaky-relu, conditioning bias, length mask, zero padding) applied once at staging; MFMA
-//   B fragments are conflict-free ds_read_b32 (lanes = consecutive time steps).
+//   A operand (weights) comes pre-packed in exact fragment order, so each lane fetches 16 bytes per MFMA group
+//   straight from global memory (L2-resident, 1 KiB per wave instruction, no LDS round trip).
+//   B operand (activations) is staged per 16 input channels into an LDS tile with the input prologue (scale,
+//   leaky-relu, conditioning bias, length mask, zero padding) applied once at staging.
 //   The next channel chunk is prefetched into registers while the current chunk is multiplied.
 //   C/D: column = time = lane & 31, so every accumulator register stores 128 contiguous bytes per half wave.
+//
+// Two arithmetic modes share tiling, prologue and epilogue:
+//   PREC_F32     v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (64 FLOP/clk/SIMD).
+//   PREC_BF16X3  every fp32 operand is split exactly into three bf16 terms (x = h + m + l, 24 significant bits) and
+//                the six largest cross products (hh, hm, mh, hl, lh, mm) run on v_mfma_f32_32x32x16_bf16 with fp32
+//                accumulation: fp32-grade results (dropped terms < 2^-24 relative) at 16/6 of the fp32 MFMA rate.
 #include "common.h"
 
 #include <cstdio>
@@ -82,9 +87,163 @@ int prof_collect(std::vector<ProfRow>& rows) {
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// VEC = true: the input rows are 16-byte aligned and L % 4 == 0, so activations are staged with dwordx4 loads and
-// ds_write_b128 (a group of four time steps is then entirely inside or entirely outside [0, L)).
+// ---------------------------------------------------------------------------------------------------------
+// Epilogue shared by both arithmetic modes (the 32x32 C/D layout does not depend on the operand type).
+// Addresses are a wave-uniform row base (scalar registers) plus ONE per-lane element offset shared by all rows.
+// All loads of a tile are issued before its first store: out may alias res (in-place residual update), so a
+// per-element load -> store sequence would serialise 16 memory round trips.
+// ---------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int MODE>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[WM][WN], const int (&mt)[WM],
+                                              const bool (&mt_ok)[WM], int wn, int par, int l31, int t0, int b,
+                                              int len_b) {
+  const float* cbias_b = a.cbias ? a.cbias + (long long)b * a.cbias_bs : nullptr;
+  float* out_b = a.out + (long long)b * a.out_bs;
+  if constexpr (MODE == MODE_PLAIN) {
+    const float* res_b = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      if (!mt_ok[i]) continue;
+      const int rowu = mt[i] * 32;
+      float bz[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowu + 4 * par + (r & 3) + 8 * (r >> 2);
+        bz[r] = a.bias ? a.bias[row] : 0.f;
+        if (cbias_b) bz[r] += cbias_b[row];
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + (wn * WN + j) * 32 + l31;
+        if (t < a.L) {
+          const float m = t < len_b ? 1.f : 0.f;
+          const unsigned lo_out = (unsigned)(4 * par * a.out_cs + t);
+          const unsigned lo_res = (unsigned)(4 * par * a.res_cs + t);
+          float rv[16], ov[16];
+          if (a.flags & (F_RES | F_RES_SUB)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              rv[r] = (res_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.res_cs)[lo_res];
+          }
+          if (a.flags & F_ACCUM) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              ov[r] = (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r] + bz[r];
+            if (a.flags & F_RELU) v = fmaxf(v, 0.f);
+            if (a.flags & F_MASK_PRE) v *= m;
+            if (a.flags & F_RES) v += rv[r];
+            if (a.flags & F_RES_SUB) v = rv[r] - v;
+            if (a.flags & F_ACCUM) v += ov[r];
+            if (a.flags & F_MASK_POST) v *= m;
+            (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = v;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one tile's loads in flight at a time: bounds the register count
+      }
+    }
+  } else if constexpr (MODE == MODE_GATE) {
+    if (mt_ok[0]) {
+      const int hrows = a.M >> 1;
+      const int rowu = mt[0] * 32;
+      float ba[16], bs[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowu + (r & 3) + 8 * (r >> 2) + 4 * par;
+        ba[r] = a.bias ? a.bias[row] : 0.f;
+        bs[r] = a.bias ? a.bias[row + hrows] : 0.f;
+        if (cbias_b) { ba[r] += cbias_b[row]; bs[r] += cbias_b[row + hrows]; }
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + (wn * WN + j) * 32 + l31;
+        if (t >= a.L) continue;
+        const unsigned lo_out = (unsigned)(4 * par * a.out_cs + t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float va = acc[0][j][r] + ba[r], vs = acc[WM - 1][j][r] + bs[r];
+          (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] =
+              tanhf(va) * (1.f / (1.f + expf(-vs)));
+        }
+      }
+    }
+  } else if constexpr (MODE == MODE_UP8 || MODE == MODE_UP4) {
+    // rows of an m-tile: 8*g + 4*par + jj  ->  channel = cb*8 + 2*g + par, phase = jj (+4 for the second class)
+    constexpr int UP = MODE == MODE_UP8 ? 8 : 4;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      if (!mt_ok[i]) continue;
+      const int cb = MODE == MODE_UP8 ? (mt[i] >> 1) : mt[i];
+      const int ph0 = MODE == MODE_UP8 ? 4 * (mt[i] & 1) : 0;
+      float bz[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bz[g] = a.bias ? a.bias[mt[i] * 32 + 8 * g + 4 * par] : 0.f;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + (wn * WN + j) * 32 + l31;
+        if (t >= a.L) continue;
+        const unsigned lo_out = (unsigned)(par * a.out_cs + UP * t + ph0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v;
+          v.x = acc[i][j][4 * g + 0] + bz[g];
+          v.y = acc[i][j][4 * g + 1] + bz[g];
+          v.z = acc[i][j][4 * g + 2] + bz[g];
+          v.w = acc[i][j][4 * g + 3] + bz[g];
+          *reinterpret_cast<float4*>(out_b + (long long)(cb * 8 + 2 * g) * a.out_cs + lo_out) = v;
+        }
+      }
+    }
+  } else {  // MODE_UP2: m-tile = 32 channels of one phase
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      if (!mt_ok[i]) continue;
+      const int cb = mt[i] >> 1, ph = mt[i] & 1;
+      float bz[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bz[r] = a.bias ? a.bias[mt[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * par] : 0.f;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + (wn * WN + j) * 32 + l31;
+        if (t >= a.L) continue;
+        const unsigned lo_out = (unsigned)(4 * par * a.out_cs + 2 * t + ph);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          (out_b + (long long)(cb * 32 + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = acc[i][j][r] + bz[r];
+      }
+    }
+  }
+}
+
+// m-tiles handled by a wave (clamped so that out-of-range tiles still read valid weights; never stored)
+template <int WM, int WGM, int MODE>
+__device__ __forceinline__ void wave_mtiles(const ConvArgs& a, int wm, int (&mt)[WM], bool (&mt_ok)[WM]) {
+  if constexpr (MODE == MODE_GATE) {
+    const int half = a.mt_total >> 1;
+    const int p = blockIdx.y * WGM + wm;
+    mt_ok[0] = mt_ok[WM - 1] = p < half;
+    mt[0] = p < half ? p : half - 1;
+    mt[WM - 1] = mt[0] + half;
+  } else {
+    const int base = (blockIdx.y * WGM + wm) * WM;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      mt_ok[i] = base + i < a.mt_total;
+      mt[i] = mt_ok[i] ? base + i : a.mt_total - 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PREC_F32 kernel.  VEC = true: the input rows are 16-byte aligned and L % 4 == 0, so activations are staged with
+// dwordx4 loads and ds_write_b128 (a group of four time steps is then entirely inside or outside [0, L)).
+// LDS tile: [16 channels][rs] fp32; MFMA B fragments are conflict-free ds_read_b32 (lanes = consecutive t).
+// ---------------------------------------------------------------------------------------------------------
 template <int WM, int WN, int WGM, int WGN, int MODE, bool VEC>
 __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int BN = 32 * WN * WGN;
@@ -107,20 +266,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
 
   int mt[WM];
   bool mt_ok[WM];
-  if constexpr (MODE == MODE_GATE) {
-    const int half = a.mt_total >> 1;
-    const int p = blockIdx.y * WGM + wm;
-    mt_ok[0] = mt_ok[WM - 1] = p < half;
-    mt[0] = p < half ? p : half - 1;
-    mt[WM - 1] = mt[0] + half;
-  } else {
-    const int base = (blockIdx.y * WGM + wm) * WM;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      mt_ok[i] = base + i < a.mt_total;
-      mt[i] = mt_ok[i] ? base + i : a.mt_total - 1;
-    }
-  }
+  wave_mtiles<WM, WGM, MODE>(a, wm, mt, mt_ok);
 
   // ---- activation staging (global -> registers -> LDS), input prologue applied on the way ----
   // LDS column c of the tile holds time step tstart + c.  VEC: tstart is rounded down to a multiple of 4.
@@ -258,145 +404,196 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
 
-  // ---- epilogue ----
-  // Addresses are a wave-uniform row base (scalar registers) plus ONE per-lane element offset shared by all rows.
-  // All loads of a tile are issued before its first store: out may alias res (in-place residual update), so a
-  // per-element load -> store sequence would serialise 16 memory round trips.
-  const float* cbias_b = a.cbias ? a.cbias + (long long)b * a.cbias_bs : nullptr;
-  float* out_b = a.out + (long long)b * a.out_bs;
-  if constexpr (MODE == MODE_PLAIN) {
-    const float* res_b = a.res ? a.res + (long long)b * a.res_bs : nullptr;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      if (!mt_ok[i]) continue;
-      const int rowu = mt[i] * 32;
-      float bz[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rowu + 4 * par + (r & 3) + 8 * (r >> 2);
-        bz[r] = a.bias ? a.bias[row] : 0.f;
-        if (cbias_b) bz[r] += cbias_b[row];
-      }
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int t = t0 + (wn * WN + j) * 32 + l31;
-        if (t < a.L) {
-          const float m = t < len_b ? 1.f : 0.f;
-          const unsigned lo_out = (unsigned)(4 * par * a.out_cs + t);
-          const unsigned lo_res = (unsigned)(4 * par * a.res_cs + t);
-          float rv[16], ov[16];
-          if (a.flags & (F_RES | F_RES_SUB)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              rv[r] = (res_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.res_cs)[lo_res];
-          }
-          if (a.flags & F_ACCUM) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              ov[r] = (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out];
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[i][j][r] + bz[r];
-            if (a.flags & F_RELU) v = fmaxf(v, 0.f);
-            if (a.flags & F_MASK_PRE) v *= m;
-            if (a.flags & F_RES) v += rv[r];
-            if (a.flags & F_RES_SUB) v = rv[r] - v;
-            if (a.flags & F_ACCUM) v += ov[r];
-            if (a.flags & F_MASK_POST) v *= m;
-            (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = v;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // one tile's loads in flight at a time: bounds the register count
-      }
-    }
-  } else if constexpr (MODE == MODE_GATE) {
-    if (mt_ok[0]) {
-      const int hrows = a.M >> 1;
-      const int rowu = mt[0] * 32;
-      float ba[16], bs[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rowu + (r & 3) + 8 * (r >> 2) + 4 * par;
-        ba[r] = a.bias ? a.bias[row] : 0.f;
-        bs[r] = a.bias ? a.bias[row + hrows] : 0.f;
-        if (cbias_b) { ba[r] += cbias_b[row]; bs[r] += cbias_b[row + hrows]; }
-      }
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int t = t0 + (wn * WN + j) * 32 + l31;
-        if (t >= a.L) continue;
-        const unsigned lo_out = (unsigned)(4 * par * a.out_cs + t);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float va = acc[0][j][r] + ba[r], vs = acc[WM - 1][j][r] + bs[r];
-          (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] =
-              tanhf(va) * (1.f / (1.f + expf(-vs)));
-        }
-      }
-    }
-  } else if constexpr (MODE == MODE_UP8 || MODE == MODE_UP4) {
-    // rows of an m-tile: 8*g + 4*par + jj  ->  channel = cb*8 + 2*g + par, phase = jj (+4 for the second class)
-    constexpr int UP = MODE == MODE_UP8 ? 8 : 4;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      if (!mt_ok[i]) continue;
-      const int cb = MODE == MODE_UP8 ? (mt[i] >> 1) : mt[i];
-      const int ph0 = MODE == MODE_UP8 ? 4 * (mt[i] & 1) : 0;
-      float bz[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) bz[g] = a.bias ? a.bias[mt[i] * 32 + 8 * g + 4 * par] : 0.f;
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int t = t0 + (wn * WN + j) * 32 + l31;
-        if (t >= a.L) continue;
-        const unsigned lo_out = (unsigned)(par * a.out_cs + UP * t + ph0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float4 v;
-          v.x = acc[i][j][4 * g + 0] + bz[g];
-          v.y = acc[i][j][4 * g + 1] + bz[g];
-          v.z = acc[i][j][4 * g + 2] + bz[g];
-          v.w = acc[i][j][4 * g + 3] + bz[g];
-          *reinterpret_cast<float4*>(out_b + (long long)(cb * 8 + 2 * g) * a.out_cs + lo_out) = v;
-        }
-      }
-    }
-  } else {  // MODE_UP2: m-tile = 32 channels of one phase
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      if (!mt_ok[i]) continue;
-      const int cb = mt[i] >> 1, ph = mt[i] & 1;
-      float bz[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bz[r] = a.bias ? a.bias[mt[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * par] : 0.f;
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int t = t0 + (wn * WN + j) * 32 + l31;
-        if (t >= a.L) continue;
-        const unsigned lo_out = (unsigned)(4 * par * a.out_cs + 2 * t + ph);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          (out_b + (long long)(cb * 32 + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = acc[i][j][r] + bz[r];
-      }
-    }
-  }
+  conv_epilogue<WM, WN, MODE>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
-template <int WM, int WN, int WGM, int WGN, int MODE, bool VEC>
-static hipError_t launch_one(ConvArgs& a, hipStream_t stream) {
+// ---------------------------------------------------------------------------------------------------------
+// PREC_BF16X3 kernel.
+// Weights: packed [Cin/16][tap][M/32][3 planes][64 lanes][8 bf16]; lane l of m-tile mt holds W[mt*32 + (l & 31)]
+//   [16*chunk + 8*(l >> 5) + j][tap], j = 0..7: the A fragment of v_mfma_f32_32x32x16_bf16, one 16-byte load per plane.
+// Activations: a thread owns a tile column; it loads the chunk's 16 channels of that time step (lanes = consecutive
+//   t, coalesced), applies the prologue, splits each value into three bf16 terms and writes them as
+//   LDS[plane][half][column][8 bf16] (16-byte units): ds_write_b128 and ds_read_b128 are both lane-contiguous.
+//   The B fragment of lane l, n-tile column c is LDS[plane][l >> 5][c] = channels 8*(l >> 5) .. +7 of that column.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack_bf16(__bf16 lo, __bf16 hi) {
+  return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+
+template <int WM, int WN, int WGM, int WGN, int MODE>
+__global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
   constexpr int BN = 32 * WN * WGN;
-  a.width = BN + (a.width);          // caller passes halo span in a.width
-  a.rs = (a.width + 3 + 3) & ~3;     // + up to 3 lead columns when the tile start is rounded down to a multiple of 4
-  const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + WM - 1) / WM;
-  dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
-  const size_t lds = (size_t)CI_CHUNK * a.rs * sizeof(float);
+  constexpr int NCT = (BN + MAX_HALO + 255) / 256;       // tile columns per thread
+  constexpr bool TWO_CLASS = (MODE == MODE_UP8 || MODE == MODE_UP2);
+  constexpr int NB = TWO_CLASS ? 2 : 1;
+  static_assert(WGM * WGN == 4, "four waves per block");
+  static_assert(!TWO_CLASS || WM == 2, "two-class transposed convs pair the classes in one wave");
+  static_assert(MODE != MODE_GATE || WM == 2, "gate pairs the tanh and sigmoid rows in one wave");
+
+  extern __shared__ __attribute__((aligned(16))) uint4 xq[];    // [3 planes][2 halves][ncols] of 8 bf16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int par = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BN;
+  const int len_b = a.lengths ? a.lengths[b] : 0x7fffffff;
+  const int ncols = a.rs;
+
+  int mt[WM];
+  bool mt_ok[WM];
+  wave_mtiles<WM, WGM, MODE>(a, wm, mt, mt_ok);
+
+  const float* xb = a.x + (long long)b * a.x_bs;
+  const int tstart = t0 + a.min_off;
+  const int wcols = a.width;
+  float st[NCT][16];
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int q = 0; q < NCT; ++q) {
+      const int col = tid + 256 * q, t = tstart + col;
+      const bool ok = col < wcols && t >= 0 && t < a.L;
+      const float* xc = xb + (long long)chunk * 16 * a.x_cs + (ok ? t : 0);
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci) {
+        const float v = xc[(long long)ci * a.x_cs];
+        st[q][ci] = ok ? v : 0.f;
+      }
+    }
+  };
+  auto store_chunk = [&](int chunk) {
+    const float* cbp = a.in_cbias ? a.in_cbias + (long long)b * a.in_cbias_bs + chunk * 16 : nullptr;
+#pragma unroll
+    for (int q = 0; q < NCT; ++q) {
+      const int col = tid + 256 * q, t = tstart + col;
+      if (col < wcols) {
+        bool ok = t >= 0 && t < a.L;
+        if (a.flags & F_IN_MASK) ok = ok && t < len_b;
+        unsigned ph[8], pm[8], pl[8];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+          __bf16 h[2], m[2], l[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int ci = 2 * c2 + u;
+            float v = (st[q][ci] + (cbp ? cbp[ci] : 0.f)) * a.in_scale;
+            if (a.flags & F_IN_LRELU) v = fmaxf(v, v * a.in_slope);
+            v = ok ? v : 0.f;
+            h[u] = (__bf16)v;                       // x = h + m + l exactly to 24 significant bits
+            const float r1 = v - (float)h[u];
+            m[u] = (__bf16)r1;
+            const float r2 = r1 - (float)m[u];
+            l[u] = (__bf16)r2;
+          }
+          ph[c2] = pack_bf16(h[0], h[1]);
+          pm[c2] = pack_bf16(m[0], m[1]);
+          pl[c2] = pack_bf16(l[0], l[1]);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          xq[(0 * 2 + hf) * ncols + col] = make_uint4(ph[4 * hf], ph[4 * hf + 1], ph[4 * hf + 2], ph[4 * hf + 3]);
+          xq[(1 * 2 + hf) * ncols + col] = make_uint4(pm[4 * hf], pm[4 * hf + 1], pm[4 * hf + 2], pm[4 * hf + 3]);
+          xq[(2 * 2 + hf) * ncols + col] = make_uint4(pl[4 * hf], pl[4 * hf + 1], pl[4 * hf + 2], pl[4 * hf + 3]);
+        }
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // weight fragments: index (((chunk*K + tap) * mt_total + mt) * 3 + plane) * 64 + lane, in 16-byte units
+  const uint4* w16 = reinterpret_cast<const uint4*>(a.w);
+  const uint4* wp[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) wp[i] = w16 + (long long)mt[i] * 192 + lane;
+  const long long it_stride = (long long)a.mt_total * 192;
+  const int nchunks = a.Cin / 16;
+  const int n_it = nchunks * a.K;
+  uint4 A[3][WM];                 // planes h, m, l of the current tap
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) A[p][i] = wp[i][p * 64];
+  int it = 0;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  auto mma = [&](const uint4 (&af)[WM], const uint4 (&bf)[NB][WN]) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                            __builtin_bit_cast(bf16x8, bf[TWO_CLASS ? i : 0][j]),
+                                                            acc[i][j], 0, 0, 0);
+  };
+
+  const int colbase = wn * WN * 32 + l31 + par * ncols - a.min_off;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+    int boff[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) boff[c] = colbase + a.toff0[c];
+    for (int k = 0; k < a.K; ++k) {
+      uint4 B[3][NB][WN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) B[p][c][j] = xq[p * 2 * ncols + boff[c] + j * 32];
+      ++it;
+      const bool more = it < n_it;
+      const long long nxt = (long long)it * it_stride;
+      // smallest terms first; each weight plane is reloaded for the next tap right after its last use
+      mma(A[2], B[0]);                                   // l * h
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) A[2][i] = wp[i][nxt + 128];
+      }
+      mma(A[1], B[1]);                                   // m * m
+      mma(A[1], B[0]);                                   // m * h
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) A[1][i] = wp[i][nxt + 64];
+      }
+      mma(A[0], B[2]);                                   // h * l
+      mma(A[0], B[1]);                                   // h * m
+      mma(A[0], B[0]);                                   // h * h
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) A[0][i] = wp[i][nxt];
+      }
+#pragma unroll
+      for (int c = 0; c < NB; ++c) boff[c] += a.tstep[c];
+    }
+    if (chunk + 1 < nchunks) {
+      __syncthreads();
+      store_chunk(chunk + 1);
+      __syncthreads();
+    }
+  }
+
+  conv_epilogue<WM, WN, MODE>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+template <typename Launch>
+static hipError_t timed_launch(const char* name, const ConvArgs& a, hipStream_t stream, Launch&& launch) {
   if (!g_prof_on) {
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE, VEC>), grid, dim3(256), lds, stream, a);
+    launch();
     return hipGetLastError();
   }
-  char name[96];
-  snprintf(name, sizeof name, "conv_mfma_kernel<%d,%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE, (int)VEC);
   hipEvent_t e0, e1;
   {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -404,7 +601,7 @@ static hipError_t launch_one(ConvArgs& a, hipStream_t stream) {
     e1 = prof_event();
   }
   (void)hipEventRecord(e0, stream);
-  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE, VEC>), grid, dim3(256), lds, stream, a);
+  launch();
   hipError_t err = hipGetLastError();
   (void)hipEventRecord(e1, stream);
   {
@@ -417,16 +614,47 @@ static hipError_t launch_one(ConvArgs& a, hipStream_t stream) {
   return err;
 }
 
+template <int WM, int WN, int WGM, int WGN, int MODE, bool VEC>
+static hipError_t launch_f32(ConvArgs& a, hipStream_t stream) {
+  constexpr int BN = 32 * WN * WGN;
+  a.width = BN + (a.width);          // caller passes halo span in a.width
+  a.rs = (a.width + 3 + 3) & ~3;     // + up to 3 lead columns when the tile start is rounded down to a multiple of 4
+  const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + WM - 1) / WM;
+  dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
+  const size_t lds = (size_t)CI_CHUNK * a.rs * sizeof(float);
+  char name[96];
+  snprintf(name, sizeof name, "conv_mfma_kernel<%d,%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE, (int)VEC);
+  return timed_launch(name, a, stream, [&] {
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE, VEC>), grid, dim3(256), lds, stream, a);
+  });
+}
+
 template <int WM, int WN, int WGM, int WGN, int MODE>
-static hipError_t launch_cfg(ConvArgs& a, hipStream_t stream) {
+static hipError_t launch_b3(ConvArgs& a, hipStream_t stream) {
+  constexpr int BN = 32 * WN * WGN;
+  a.width = BN + (a.width);
+  a.rs = a.width;                    // columns per (plane, half) slab
+  const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + WM - 1) / WM;
+  dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
+  const size_t lds = (size_t)6 * a.rs * sizeof(uint4);
+  char name[96];
+  snprintf(name, sizeof name, "conv_bf16x3_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
+  return timed_launch(name, a, stream, [&] {
+    hipLaunchKernelGGL((conv_bf16x3_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
+  });
+}
+
+template <int WM, int WN, int WGM, int WGN, int MODE>
+static hipError_t launch_cfg(ConvArgs& a, int prec, hipStream_t stream) {
+  if (prec == PREC_BF16X3) return launch_b3<WM, WN, WGM, WGN, MODE>(a, stream);
   // dwordx4 staging needs 16-byte aligned rows and whole groups of four time steps
   const bool vec = a.L % 4 == 0 && a.x_cs % 4 == 0 && a.x_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
-  if (vec) return launch_one<WM, WN, WGM, WGN, MODE, true>(a, stream);
-  return launch_one<WM, WN, WGM, WGN, MODE, false>(a, stream);
+  if (vec) return launch_f32<WM, WN, WGM, WGN, MODE, true>(a, stream);
+  return launch_f32<WM, WN, WGM, WGN, MODE, false>(a, stream);
 }
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
-  if (d.Cin % CI_CHUNK != 0 || d.M % 32 != 0 || d.K < 1 || d.K > MAX_TAPS) return hipErrorInvalidValue;
+  if (d.Cin % 16 != 0 || d.M % 32 != 0 || d.K < 1 || d.K > MAX_TAPS) return hipErrorInvalidValue;
   if (d.max_off - d.min_off > MAX_HALO) return hipErrorInvalidValue;
   if (a.B <= 0 || a.L <= 0) return hipErrorInvalidValue;
   if (a.B > 65535) return hipErrorInvalidValue;
@@ -442,33 +670,33 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
     a.toff0[c] = d.toff0[c];
     a.tstep[c] = d.tstep[c];
   }
-  const int L = a.L, M = d.M;
+  const int L = a.L, M = d.M, p = d.prec;
   switch (d.mode) {
     case MODE_PLAIN:
       if (M % 64 == 0) {
-        if (L <= 96 && M % 128 == 0) return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, stream);
+        if (L <= 96 && M % 128 == 0) return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, p, stream);
         // taller block tiles when there are enough rows: one staged activation tile then feeds 128 / 256 rows
-        if (M % 256 == 0) return launch_cfg<2, 2, 4, 1, MODE_PLAIN>(a, stream);
-        if (M % 128 == 0) return launch_cfg<2, 2, 2, 2, MODE_PLAIN>(a, stream);
-        return launch_cfg<2, 2, 1, 4, MODE_PLAIN>(a, stream);
+        if (M % 256 == 0) return launch_cfg<2, 2, 4, 1, MODE_PLAIN>(a, p, stream);
+        if (M % 128 == 0) return launch_cfg<2, 2, 2, 2, MODE_PLAIN>(a, p, stream);
+        return launch_cfg<2, 2, 1, 4, MODE_PLAIN>(a, p, stream);
       }
-      if (L > 1024) return launch_cfg<1, 4, 1, 4, MODE_PLAIN>(a, stream);
-      if (L > 192) return launch_cfg<1, 2, 1, 4, MODE_PLAIN>(a, stream);
-      return launch_cfg<1, 1, 1, 4, MODE_PLAIN>(a, stream);
+      if (L > 1024 && p == PREC_F32) return launch_cfg<1, 4, 1, 4, MODE_PLAIN>(a, p, stream);
+      if (L > 192) return launch_cfg<1, 2, 1, 4, MODE_PLAIN>(a, p, stream);
+      return launch_cfg<1, 1, 1, 4, MODE_PLAIN>(a, p, stream);
     case MODE_GATE:
       if (M % 64 != 0) return hipErrorInvalidValue;
-      if (L <= 96) return launch_cfg<2, 1, 2, 2, MODE_GATE>(a, stream);
-      return launch_cfg<2, 2, 1, 4, MODE_GATE>(a, stream);
+      if (L <= 96) return launch_cfg<2, 1, 2, 2, MODE_GATE>(a, p, stream);
+      return launch_cfg<2, 2, 1, 4, MODE_GATE>(a, p, stream);
     case MODE_UP8:
       if (M % 64 != 0) return hipErrorInvalidValue;
-      if (L <= 1024) return launch_cfg<2, 1, 2, 2, MODE_UP8>(a, stream);
-      return launch_cfg<2, 2, 1, 4, MODE_UP8>(a, stream);
+      if (L <= 1024) return launch_cfg<2, 1, 2, 2, MODE_UP8>(a, p, stream);
+      return launch_cfg<2, 2, 1, 4, MODE_UP8>(a, p, stream);
     case MODE_UP4:
       if (M % 64 != 0) return hipErrorInvalidValue;
-      return launch_cfg<2, 2, 1, 4, MODE_UP4>(a, stream);
+      return launch_cfg<2, 2, 1, 4, MODE_UP4>(a, p, stream);
     case MODE_UP2:
       if (M % 64 != 0) return hipErrorInvalidValue;
-      return launch_cfg<2, 2, 1, 4, MODE_UP2>(a, stream);
+      return launch_cfg<2, 2, 1, 4, MODE_UP2>(a, p, stream);
     default:
       return hipErrorInvalidValue;
   }

@@ -96,7 +96,8 @@ struct Arena {
 
 inline int64_t pad256(int64_t floats) { return (floats * 4 + 255) & ~int64_t(255); }
 
-int make_desc(ConvDesc& d, const float* w, const float* bias, int cin, int rows, int taps, int dilation, int mode) {
+int make_desc(ConvDesc& d, const void* w, const float* bias, int cin, int rows, int taps, int dilation, int mode,
+              int prec = PREC_F32) {
   if (cin <= 0 || cin % CI_CHUNK || rows <= 0 || rows % 32 || taps < 1 || taps > MAX_TAPS || dilation < 1)
     return fail(VITS_ERR_INVALID, "conv: cin must be a multiple of 16, rows of 32, 1 <= taps <= 12");
   d = ConvDesc();
@@ -106,6 +107,8 @@ int make_desc(ConvDesc& d, const float* w, const float* bias, int cin, int rows,
   d.M = rows;
   d.K = taps;
   d.mode = mode;
+  if (prec != PREC_F32 && prec != PREC_BF16X3) return fail(VITS_ERR_INVALID, "conv: unknown precision");
+  d.prec = prec;
   switch (mode) {
     case MODE_PLAIN:
     case MODE_GATE:
@@ -279,11 +282,11 @@ int vits_model_set_tensor(vits_model* m, const char* name, const float* p, int64
   return VITS_OK;
 }
 
-int vits_model_set_conv(vits_model* m, const char* name, const float* w, const float* bias, int cin, int rows, int taps,
-                        int dilation, int mode) {
+int vits_model_set_conv(vits_model* m, const char* name, const void* w, const float* bias, int cin, int rows, int taps,
+                        int dilation, int mode, int precision) {
   if (!m || !name || !w) return fail(VITS_ERR_INVALID, "set_conv: bad argument");
   ConvDesc d;
-  TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode));
+  TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode, precision));
   m->convs[name] = d;
   m->finalized = false;
   return VITS_OK;
@@ -399,6 +402,50 @@ int vits_pack_conv_weight(const float* w, int rows, int cin, int taps, float* ou
               const int ci = chunk * CI_CHUNK + sq * 8 + e * 2 + (lane >> 5);
               out[o++] = w[((int64_t)row * cin + ci) * taps + k];
             }
+  return VITS_OK;
+}
+
+// round-to-nearest-even fp32 -> bf16 (bit pattern) and back, on the host
+static inline uint16_t f2bf(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf2f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+int vits_pack_conv_weight_bf16x3(const float* w, int rows, int cin, int taps, uint16_t* out) {
+  if (!w || !out || rows <= 0 || rows % 32 || cin <= 0 || cin % 16 || taps < 1)
+    return fail(VITS_ERR_INVALID, "pack: rows % 32 == 0 and cin % 16 == 0 required");
+  // [cin/16][taps][rows/32][3 planes][64 lanes][8]: lane l of m-tile mt holds, for j = 0..7, the three bf16 terms
+  // (h, m, l with h + m + l = w to 24 bits) of W[mt*32 + (l & 31)][16*chunk + 8*(l >> 5) + j][tap]
+  const int mt_total = rows / 32, nchunks = cin / 16;
+  int64_t o = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk)
+    for (int k = 0; k < taps; ++k)
+      for (int mt = 0; mt < mt_total; ++mt) {
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int row = mt * 32 + (lane & 31);
+            const int ci = chunk * 16 + 8 * (lane >> 5) + j;
+            const float v = w[((int64_t)row * cin + ci) * taps + k];
+            const uint16_t h = f2bf(v);
+            const float r1 = v - bf2f(h);
+            const uint16_t m = f2bf(r1);
+            const float r2 = r1 - bf2f(m);
+            const uint16_t l = f2bf(r2);
+            out[o + (0 * 64 + lane) * 8 + j] = h;
+            out[o + (1 * 64 + lane) * 8 + j] = m;
+            out[o + (2 * 64 + lane) * 8 + j] = l;
+          }
+        o += 3 * 64 * 8;
+      }
   return VITS_OK;
 }
 
@@ -663,11 +710,11 @@ int vits_profile_read(int index, char* name, int name_len, double* flops, double
 }
 
 // ---- single operators ----
-int vits_op_conv1d(const float* w, const float* bias, int cin, int rows, int taps, int dilation, int mode, const float* x,
-                   int B, int L, const int* lengths, const float* cbias, const float* in_cbias, const float* res,
-                   float* out, int flags, float in_scale, float in_slope, void* stream) {
+int vits_op_conv1d(const void* w, const float* bias, int cin, int rows, int taps, int dilation, int mode, int precision,
+                   const float* x, int B, int L, const int* lengths, const float* cbias, const float* in_cbias,
+                   const float* res, float* out, int flags, float in_scale, float in_slope, void* stream) {
   ConvDesc d;
-  TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode));
+  TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode, precision));
   return conv_simple(d, x, out, B, L, lengths, flags, (hipStream_t)stream, res, cbias, rows, in_cbias, cin, in_scale,
                      in_slope);
 }

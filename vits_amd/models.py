@@ -9,6 +9,7 @@ GPU this module raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -32,6 +33,11 @@ class SynthesizerTrn:
             raise NotImplementedError("only resblock='1' (ResBlock1) is implemented; the reference config uses it")
         if n_speakers <= 1 or gin_channels <= 0:
             raise NotImplementedError("a speaker-conditioned model (n_speakers > 1, gin_channels > 0) is required")
+        # arithmetic of the conv kernels: "bf16x3" (default) or "fp32"; keyword `precision` or env VITS_PRECISION
+        prec = kwargs.pop("precision", None) or os.environ.get("VITS_PRECISION", "bf16x3")
+        if prec not in N.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(N.PRECISIONS)}")
+        self.precision = prec
         self.cfg = synthetic.ModelConfig(
             n_vocab=n_vocab, spec_channels=spec_channels, hop_length=hop_length, sampling_rate=sampling_rate,
             segment_size=segment_size, inter_channels=inter_channels, hidden_channels=hidden_channels,
@@ -134,7 +140,7 @@ class SynthesizerTrn:
     def _upload(self):
         if not torch.cuda.is_available():
             raise RuntimeError("vits_amd needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
-        pw = weights.prepare(self._sd, self.cfg)
+        pw = weights.prepare(self._sd, self.cfg, N.PRECISIONS[self.precision])
         self._device_tensors = []
         h = self._handle
         with torch.cuda.device(self.device):
@@ -146,7 +152,8 @@ class SynthesizerTrn:
                 dw = w.to(self.device)
                 db = None if b is None else b.to(self.device)
                 self._device_tensors += [dw, db]
-                N.check(N.lib.vits_model_set_conv(h, name.encode(), dw.data_ptr(), N.ptr(db), cin, rows, taps, dil, mode),
+                N.check(N.lib.vits_model_set_conv(h, name.encode(), dw.data_ptr(), N.ptr(db), cin, rows, taps, dil, mode,
+                                                  pw.precision),
                         f"set_conv {name}")
             N.check(N.lib.vits_model_finalize(h), "vits_model_finalize")
             torch.cuda.synchronize(self.device)

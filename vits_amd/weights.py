@@ -31,10 +31,15 @@ def folded(sd: Dict[str, torch.Tensor], base: str) -> torch.Tensor:
     raise KeyError(f"{base}.weight (or weight_g / weight_v) is not in the checkpoint")
 
 
-def pack_rows(w_rows: torch.Tensor) -> torch.Tensor:
-    """[rows, cin, taps] fp32 (CPU) -> flat packed fragment order used by the conv kernel."""
+def pack_rows(w_rows: torch.Tensor, precision: int = N.PREC_F32) -> torch.Tensor:
+    """[rows, cin, taps] fp32 (CPU) -> flat packed fragment order used by the conv kernel (fp32, or three bf16
+    planes stored as int16 bit patterns for the bf16x3 mode)."""
     w_rows = w_rows.contiguous().float()
     rows, cin, taps = w_rows.shape
+    if precision == N.PREC_BF16X3:
+        out = torch.empty(3 * rows * cin * taps, dtype=torch.int16)
+        N.check(N.lib.vits_pack_conv_weight_bf16x3(w_rows.data_ptr(), rows, cin, taps, out.data_ptr()), "pack_bf16x3")
+        return out
     out = torch.empty(rows * cin * taps, dtype=torch.float32)
     N.check(N.lib.vits_pack_conv_weight(w_rows.data_ptr(), rows, cin, taps, out.data_ptr()), "pack_conv_weight")
     return out
@@ -92,7 +97,8 @@ def transposed_conv_rows(wt: torch.Tensor, bias: torch.Tensor, stride: int, kern
 class PreparedWeights:
     """CPU-side result of preparing a checkpoint: plain tensors and packed convs keyed by library names."""
 
-    def __init__(self):
+    def __init__(self, precision: int = N.PREC_F32):
+        self.precision = precision
         self.plain: Dict[str, torch.Tensor] = {}
         self.convs: Dict[str, Tuple[torch.Tensor, torch.Tensor, int, int, int, int, int]] = {}
 
@@ -102,17 +108,17 @@ class PreparedWeights:
     def add_conv(self, name: str, w_rows: torch.Tensor, bias_rows, dilation: int = 1, mode: int = N.MODE_PLAIN):
         rows, cin, taps = w_rows.shape
         b = None if bias_rows is None else bias_rows.detach().float().contiguous()
-        self.convs[name] = (pack_rows(w_rows), b, cin, rows, taps, dilation, mode)
+        self.convs[name] = (pack_rows(w_rows, self.precision), b, cin, rows, taps, dilation, mode)
 
 
 ENCODERS = (("enc_p.encoder", "n_layers"), ("pitch_predictor.pitch_net", "pitch_layers"),
             ("frame_prior_net.fft_block", "n_layers"))
 
 
-def prepare(sd: Dict[str, torch.Tensor], cfg) -> PreparedWeights:
+def prepare(sd: Dict[str, torch.Tensor], cfg, precision: int = N.PREC_F32) -> PreparedWeights:
     """cfg: vits_amd.synthetic.ModelConfig-like object with the model dimensions."""
     sd = {k: v.detach().cpu() for k, v in sd.items()}
-    pw = PreparedWeights()
+    pw = PreparedWeights(precision)
     C, G = cfg.hidden_channels, cfg.gin_channels
 
     def bias(base):
