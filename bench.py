@@ -8,7 +8,9 @@ workload is BASELINE.json's configs[1]: 16 utterances of 50 phonemes / 258 frame
 fp32, fixed MFA-style durations, fixed noise; every rank runs its own batch (utterance-level data parallelism, no
 collective on the data path, weak scaling).  Rank 0 prints one JSON line:
   value      = audio-seconds synthesised per wall-second, summed over ranks (max-over-ranks time)
-  roofline   = the dominant kernel (the fp32 MFMA conv) timed with HIP events on its launch stream
+  roofline   = the dominant kernel (the MFMA conv instantiation with the largest summed time) timed with HIP events on
+               its launch stream; algorithmic fp32 FLOP/s against the dense MFMA peak of the mode it runs in
+               (fp32 MFMA: 157.3 TFLOP/s; bf16x3: six bf16 products per fp32 product, 2500 / 6 = 416.7 TFLOP/s)
   cpu_baseline = the CPU oracle (a PyTorch fp32 port of the reference's infer) timed on this host's cores on a
                  bounded sample of the same workload
 """
@@ -24,6 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (256 CUs x 256 FLOP/clk x 2.4 GHz)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 matrix peak
+# bf16x3 kernels spend six bf16 MFMA products per algorithmic fp32 product
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def build_model(device):
@@ -82,6 +87,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency section (profiling runs)")
+    ap.add_argument("--serial-generator", action="store_true",
+                    help="keep the generator's ResBlock chains on one stream (rocprofv3 runs: per-kernel durations "
+                         "then do not overlap and match the event-timed roofline pass)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +107,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
+    if args.serial_generator:
+        os.environ["VITS_GEN_STREAMS"] = "1"
     from vits_amd import _native as N
     from vits_amd import synthetic
     net = build_model(device)
@@ -137,8 +147,9 @@ def main():
         dom = rows[0]
         conv_ms = sum(r["ms"] for r in rows)
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+        peak = PEAK_FP32_MFMA_TFLOPS if dom["name"].startswith("conv_mfma_kernel") else PEAK_BF16X3_TFLOPS
+        roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(achieved, 3), peak=round(peak, 1),
+                        unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
                         launches_per_step=dom["count"] // args.steps,
                         avg_launch_us=round(dom["ms"] * 1e3 / dom["count"], 2),
                         flops_per_launch=round(dom["flops"] / dom["count"]),
@@ -174,6 +185,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "conv_precision": net.precision,
             "data": "synthetic",
             "config": {"workload": f"C2: batch {args.batch} x 50 phonemes x 258 frames (3.0 s each), fixed durations, "
                                    "fixed noise, fp32; one batch per GPU per step",

@@ -120,7 +120,9 @@ int vits_generator(const vits_model* m, const float* z, const int* frame_lengths
 /* ---- per-kernel timing of the conv launches (HIP events on the launch stream; off by default).  No counterpart
  * in the reference.  vits_profile_read(-1, ...) resolves pending events (synchronises) and returns the number of
  * rows; vits_profile_read(i, ...) returns row i: kernel instantiation name, summed algorithmic FLOPs
- * (2 * rows * cin * taps * L * B per launch), summed milliseconds and launch count since the last reset. */
+ * (2 * rows * cin * taps * L * B per launch), summed milliseconds and launch count since the last reset.
+ * While timing is enabled vits_generator keeps all its launches on the caller's stream (no side streams), so the
+ * per-kernel intervals do not overlap. */
 void vits_profile_enable(int on);
 void vits_profile_reset(void);
 int vits_profile_read(int index, char* name, int name_len, double* flops, double* ms, int64_t* count);

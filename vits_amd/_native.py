@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvits_amd.so")
+LIB_PATH = os.environ.get("VITS_AMD_LIB") or os.path.join(_HERE, "lib", "libvits_amd.so")
 
 
 class VitsConfig(C.Structure):

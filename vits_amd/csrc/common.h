@@ -76,6 +76,7 @@ struct ProfRow {
   long long count;
 };
 void prof_enable(bool on);
+bool prof_enabled();
 void prof_reset();
 int prof_collect(std::vector<ProfRow>& rows);
 

@@ -651,6 +651,8 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
     if (!Y[j] || !Tt[j]) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
   }
   if (!X || !XS) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
+  // per-kernel event timing needs the launches of one step serialised on one stream
+  const int n_side = prof_enabled() ? 0 : m->n_side;
   // conv_pre on (z * mask)[:, :, :t_dec] + cond(g)   (reference models.py:285-287, 765)
   {
     ConvArgs a = base_args(z, (long long)IC * T, T, XS, (long long)ch0 * t_dec, t_dec, B, t_dec, lengths, F_IN_MASK);
@@ -666,12 +668,12 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
     // The nk ResBlocks read the same x and are independent until their outputs are summed (models.py:292-298):
     // chain j runs on its own stream; its last conv accumulates into XS after chain j-1's has (same order of
     // additions as the reference: (rb0 + rb1) + rb2).
-    if (m->n_side > 0) {
+    if (n_side > 0) {
       HIP_TRY(hipEventRecord(m->ev_fork, s));
-      for (int j = 0; j < m->n_side; ++j) HIP_TRY(hipStreamWaitEvent(m->side[j], m->ev_fork, 0));
+      for (int j = 0; j < n_side; ++j) HIP_TRY(hipStreamWaitEvent(m->side[j], m->ev_fork, 0));
     }
     for (int j = 0; j < nk; ++j) {
-      hipStream_t sj = (j == 0 || m->n_side == 0) ? s : m->side[std::min(j, m->n_side) - 1];
+      hipStream_t sj = (j == 0 || n_side == 0) ? s : m->side[std::min(j, n_side) - 1];
       const ResBlock& rb = m->rbs[i * nk + j];
       const float* yin = X;
       for (int q = 0; q < nd; ++q) {
@@ -679,13 +681,13 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
         const bool last = q + 1 == nd;
         float* dst = last ? XS : Y[j];
         const int flags = F_IN_LRELU | F_RES | (last && j > 0 ? F_ACCUM : 0);
-        if (last && j > 0 && m->n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
+        if (last && j > 0 && n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
         TRY(conv_simple(rb.c2[q], Tt[j], dst, B, L, nullptr, flags, sj, yin, nullptr, 0, nullptr, 0, 1.f, 0.1f));
         yin = Y[j];
       }
-      if (m->n_side > 0) HIP_TRY(hipEventRecord(m->ev_done[j], sj));
+      if (n_side > 0) HIP_TRY(hipEventRecord(m->ev_done[j], sj));
     }
-    if (m->n_side > 0) HIP_TRY(hipStreamWaitEvent(s, m->ev_done[nk - 1], 0));
+    if (n_side > 0) HIP_TRY(hipStreamWaitEvent(s, m->ev_done[nk - 1], 0));
     in_scale = 1.f / (float)nk;
   }
   // tanh(conv_post(leaky_relu(x, 0.01)))   (reference models.py:299-301)
