@@ -960,6 +960,226 @@ static hipError_t launch_b3(ConvArgs& a, hipStream_t stream) {
   });
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// PREC_BF16X3, split-K kernel for short sequences (MODE_PLAIN / MODE_GATE).
+//
+// At phoneme and frame rate (L = 50 .. a few hundred) a conv has few output tiles but a deep reduction (up to
+// 768 channels x 3 taps), and the one-role kernel walks that reduction as one serial chain per block.  Here the four
+// waves of a block all own the SAME 64 x (32 * WN) output tile and split the channel chunks between them
+// (wave w takes chunks w, w + 4, ...): each wave stages its chunks into a private LDS region, so the main loop has no
+// block barrier at all, and the chain is a quarter as long.  The four partial accumulators are then summed through LDS
+// in a fixed order ((w0 + w2) + (w1 + w3)) and wave 0 runs the epilogue.
+// ---------------------------------------------------------------------------------------------------------
+template <int WN, int MODE>
+__global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const ConvArgs a) {
+  constexpr int WM = 2;
+  constexpr int BN = 32 * WN;
+  constexpr int NCT = (BN + MAX_HALO + 63) / 64;             // tile columns per lane
+  static_assert(MODE == MODE_PLAIN || MODE == MODE_GATE, "one row class only");
+
+  extern __shared__ __attribute__((aligned(16))) uint4 xq[];    // [4 waves][3 planes][2 halves][ncols] of 8 bf16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int par = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BN;
+  const int len_b = a.lengths ? a.lengths[b] : 0x7fffffff;
+  const int ncols = a.rs;
+  uint4* xw = xq + wave * 6 * ncols;
+
+  int mt[WM];
+  bool mt_ok[WM];
+  if constexpr (MODE == MODE_GATE) {
+    const int half = a.mt_total >> 1;
+    const int p = blockIdx.y;
+    mt_ok[0] = mt_ok[1] = p < half;
+    mt[0] = p < half ? p : half - 1;
+    mt[1] = mt[0] + half;
+  } else {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      mt_ok[i] = (int)blockIdx.y * WM + i < a.mt_total;
+      mt[i] = mt_ok[i] ? (int)blockIdx.y * WM + i : a.mt_total - 1;
+    }
+  }
+
+  const float* xb = a.x + (long long)b * a.x_bs;
+  const int tstart = t0 + a.min_off;
+  const int wcols = a.width;
+  float st[NCT][16];
+  auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NCT; ++q) {
+      const int col = lane + 64 * q, t = tstart + col;
+      const unsigned toff = (col < wcols && t >= 0 && t < a.L) ? (unsigned)t : 0u;
+      const float* xc = xb + (long long)chunk * 16 * a.x_cs;
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci) st[q][ci] = (xc + (long long)ci * a.x_cs)[toff];    // raw: store_chunk zeroes
+    }
+  };
+  auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NCT; ++q) {
+      const int col = lane + 64 * q, t = tstart + col;
+      bool ok = t >= 0 && t < a.L;
+      if (a.flags & F_IN_MASK) ok = ok && t < len_b;
+      unsigned ph[8], pm[8], pl[8];
+#pragma unroll
+      for (int c2 = 0; c2 < 8; ++c2) {
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float x = st[q][2 * c2 + u] * a.in_scale;
+          if (a.flags & F_IN_LRELU) x = fmaxf(x, x * a.in_slope);
+          v[u] = ok ? x : 0.f;
+        }
+        split3_pair(v[0], v[1], ph[c2], pm[c2], pl[c2]);
+      }
+      if (col < wcols) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          xw[(0 * 2 + hf) * ncols + col] = make_uint4(ph[4 * hf], ph[4 * hf + 1], ph[4 * hf + 2], ph[4 * hf + 3]);
+          xw[(1 * 2 + hf) * ncols + col] = make_uint4(pm[4 * hf], pm[4 * hf + 1], pm[4 * hf + 2], pm[4 * hf + 3]);
+          xw[(2 * 2 + hf) * ncols + col] = make_uint4(pl[4 * hf], pl[4 * hf + 1], pl[4 * hf + 2], pl[4 * hf + 3]);
+        }
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const uint4* w16 = reinterpret_cast<const uint4*>(a.w);
+  unsigned wofs[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) wofs[i] = (unsigned)(mt[i] * 192 + lane);
+  const long long it_stride = (long long)a.mt_total * 192;
+  const int nchunks = a.Cin / 16;
+  const int my_chunks = nchunks > wave ? (nchunks - wave + 3) / 4 : 0;
+  const int colbase = l31 + par * ncols - a.min_off;
+
+  uint4 Ah[2][WM], Am[2][WM], Al[WM], Bh[2][WN], Bm[2][WN], Bl[WN];
+  auto lda = [&](uint4 (&d)[WM], long long base, int plane) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) d[i] = (w16 + base + plane * 64)[wofs[i]];
+  };
+  auto ldb = [&](uint4 (&d)[WN], int plane, int off) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) d[j] = xw[plane * 2 * ncols + off + j * 32];
+  };
+  auto mma = [&](const uint4 (&af)[WM], const uint4 (&bf)[WN]) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                            __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+  };
+
+  if (my_chunks > 0) {
+    int chunk = wave, k = 0, boff = colbase + a.toff0[0];
+    const long long w0 = (long long)chunk * a.K * it_stride;
+    lda(Ah[0], w0, 0);
+    lda(Am[0], w0, 1);
+    lda(Al, w0, 2);
+    load_chunk(chunk);
+    store_chunk();
+    if (chunk + 4 < nchunks) load_chunk(chunk + 4);
+    ldb(Bh[0], 0, boff);
+    ldb(Bm[0], 1, boff);
+    ldb(Bl, 2, boff);
+
+    // One tap with register set c current and set n prefetched (same schedule as the wave-specialised consumer).
+    auto step = [&](auto P) __attribute__((always_inline)) {
+      constexpr int c = decltype(P)::value, n = c ^ 1;
+      const bool last = k == a.K - 1;
+      // next tap: the same chunk, or tap 0 of this wave's next chunk (clamped to the last one at the very end)
+      const int nchunk = last ? (chunk + 4 < nchunks ? chunk + 4 : chunk) : chunk;
+      const int nk = last ? 0 : k + 1;
+      const long long wb = ((long long)nchunk * a.K + nk) * it_stride;
+      const int boffn = last ? boff : boff + a.tstep[0];
+      lda(Ah[n], wb, 0);
+      lda(Am[n], wb, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(Ah[c], Bl);                                           // h * l
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last) {
+        ldb(Bh[n], 0, boffn);
+        ldb(Bm[n], 1, boffn);
+        ldb(Bl, 2, boffn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(Al, Bh[c]);                                           // l * h
+      __builtin_amdgcn_sched_barrier(0);
+      lda(Al, wb, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(Am[c], Bm[c]);                                        // m * m
+      mma(Ah[c], Bm[c]);                                        // h * m
+      mma(Am[c], Bh[c]);                                        // m * h
+      mma(Ah[c], Bh[c]);                                        // h * h
+      __builtin_amdgcn_sched_barrier(0);
+      k = nk;
+      boff = boffn;
+      if (last) {
+        // this wave's LDS region is free (its reads were consumed by the MFMAs above): stage the next chunk
+        const bool more = chunk + 4 < nchunks;
+        chunk += 4;
+        boff = colbase + a.toff0[0];
+        if (more) {
+          store_chunk();
+          if (chunk + 4 < nchunks) load_chunk(chunk + 4);
+          ldb(Bh[n], 0, boff);
+          ldb(Bm[n], 1, boff);
+          ldb(Bl, 2, boff);
+        }
+      }
+    };
+    const int S = my_chunks * a.K;
+    int s = 0;
+    for (; s + 1 < S; s += 2) {
+      step(IntC<0>{});
+      step(IntC<1>{});
+    }
+    if (s < S) step(IntC<0>{});
+  }
+
+  // ---- fixed-order reduction of the four partial sums through LDS: (w0 + w2) + (w1 + w3) ----
+  __syncthreads();                                              // every wave is done with its staging region
+  float* red = reinterpret_cast<float*>(xq);                    // [2 slots][WM * WN * 16][64 lanes]
+  constexpr int NACC = WM * WN * 16;
+  auto put = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(slot * NACC + (i * WN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  };
+  auto add = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(slot * NACC + (i * WN + j) * 16 + r) * 64 + lane];
+  };
+  if (wave >= 2) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) add(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave == 0) {
+    add(0);
+    conv_epilogue<WM, WN, MODE>(a, acc, mt, mt_ok, 0, par, l31, t0, b, len_b);
+  }
+}
+
 static int device_cu_count() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -1002,6 +1222,49 @@ static hipError_t launch_b3ws(ConvArgs& a, hipStream_t stream) {
   });
 }
 
+// VITS_CONV_KS=0 keeps short sequences on the one-role kernel (for A/B measurements).
+static bool ks_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_CONV_KS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+template <int WN, int MODE>
+static hipError_t launch_b3ks(ConvArgs& a, hipStream_t stream) {
+  constexpr int BN = 32 * WN;
+  a.width = BN + (a.width);
+  a.rs = a.width;
+  const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + 1) / 2;
+  dim3 grid((a.L + BN - 1) / BN, units, a.B);
+  const size_t stage = (size_t)4 * 6 * a.rs * sizeof(uint4), red = (size_t)WN * 16384;
+  const size_t lds = stage > red ? stage : red;
+  char name[96];
+  snprintf(name, sizeof name, "conv_b3ks_kernel<%d,%d>", WN, MODE);
+  return timed_launch(name, a, stream, [&] {
+    hipLaunchKernelGGL((conv_b3ks_kernel<WN, MODE>), grid, dim3(256), lds, stream, a);
+  });
+}
+
+// Split-K is for launches whose one-role grid would leave most CUs with a single long reduction chain: few output
+// tiles (at most two blocks per CU) and at least four channel chunks to share out.  Returns false when it does not apply.
+template <int MODE>
+static bool try_launch_ks(ConvArgs& a, hipStream_t stream, hipError_t& err) {
+  if (!ks_enabled() || a.M % 64 != 0 || a.Cin < 64 || a.in_cbias) return false;
+  const int n32 = (a.L + 31) / 32;
+  int wn = 1, best = n32;                                   // fewest padded 32-column tiles, then the widest tile
+  for (int c = 2; c <= 3; ++c) {
+    const int padded = (n32 + c - 1) / c * c;
+    if (padded <= best) { best = padded; wn = c; }
+  }
+  const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + 1) / 2;
+  const long long blocks = (long long)((n32 + wn - 1) / wn) * units * a.B;
+  if (blocks > 2LL * device_cu_count()) return false;
+  err = wn == 1 ? launch_b3ks<1, MODE>(a, stream) : wn == 2 ? launch_b3ks<2, MODE>(a, stream) : launch_b3ks<3, MODE>(a, stream);
+  return true;
+}
+
 template <int WM, int WN, int WGM, int WGN, int MODE>
 static hipError_t launch_cfg(ConvArgs& a, int prec, hipStream_t stream) {
   if constexpr (WM == 2 && WN == 2 && (MODE == MODE_PLAIN || MODE == MODE_GATE)) {
@@ -1035,6 +1298,12 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
     a.tstep[c] = d.tstep[c];
   }
   const int L = a.L, M = d.M, p = d.prec;
+  if (p == PREC_BF16X3 && (d.mode == MODE_PLAIN || d.mode == MODE_GATE)) {
+    hipError_t err = hipSuccess;
+    ConvArgs ak = a;
+    if (d.mode == MODE_PLAIN ? try_launch_ks<MODE_PLAIN>(ak, stream, err) : try_launch_ks<MODE_GATE>(ak, stream, err))
+      return err;
+  }
   switch (d.mode) {
     case MODE_PLAIN:
       if (M % 64 == 0) {
