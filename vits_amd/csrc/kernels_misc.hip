@@ -9,47 +9,71 @@ namespace vits {
 
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm over channels of [B, C, L]  (reference modules.py:15-27; nn.LayerNorm in frame_prior_network.py:83,95)
-// biased variance, eps inside the sqrt.  Block = 64 time steps x 4 waves splitting the channels.
+// biased variance, eps inside the sqrt.
+// Block = 16 time steps x 16 channel groups: thread (t, g) keeps channels g, g + 16, ... (NV of them) in registers,
+// so x is read once, every load of a thread is independent and in flight together, and the two reductions (mean,
+// then the centred sum of squares) run over registers: shuffles across the four groups of a wave, LDS across waves.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <int NV>
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* x, float* y,   // x may be y (in place)
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const int* __restrict__ lengths, int C, int L, int mask_out) {
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.y, t = blockIdx.x * 64 + lane;
+  __shared__ float red[2][4][16];
+  const int tl = threadIdx.x & 15, g = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t = blockIdx.x * 16 + tl;
   const bool valid = t < L;
-  const float* xb = x + (long long)b * C * L + t;
-  float* yb = y + (long long)b * C * L + t;
+  const float* xb = x + (long long)b * C * L + (valid ? t : 0);
+  float v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = g + 16 * i;
+    v[i] = c < C ? xb[(long long)c * L] : 0.f;
+  }
+  auto block_sum = [&](float s, int slot) {
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if ((threadIdx.x & 63) < 16) red[slot][wave][tl] = s;
+    __syncthreads();
+    return red[slot][0][tl] + red[slot][1][tl] + red[slot][2][tl] + red[slot][3][tl];
+  };
   float s = 0.f;
-  for (int c = wave; c < C; c += 4) s += valid ? xb[(long long)c * L] : 0.f;
-  red[wave][lane] = s;
-  __syncthreads();
-  const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
-  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += v[i];
+  const float mean = block_sum(s, 0) / (float)C;
   s = 0.f;
-  for (int c = wave; c < C; c += 4) {
-    const float d = (valid ? xb[(long long)c * L] : 0.f) - mean;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float d = g + 16 * i < C ? v[i] - mean : 0.f;
     s += d * d;
   }
-  red[wave][lane] = s;
-  __syncthreads();
-  const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  const float var = block_sum(s, 1) / (float)C;
   const float rstd = 1.f / sqrtf(var + 1e-5f);
-  const bool keep = !mask_out || (lengths && t < lengths[b]) || !lengths;
+  const bool keep = !mask_out || !lengths || t < lengths[b];
   if (valid) {
-    for (int c = wave; c < C; c += 4) {
-      const float v = (xb[(long long)c * L] - mean) * rstd * gamma[c] + beta[c];
-      yb[(long long)c * L] = keep ? v : 0.f;
+    float* yb = y + (long long)b * C * L + t;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = g + 16 * i;
+      if (c < C) {
+        const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        yb[(long long)c * L] = keep ? o : 0.f;
+      }
     }
   }
 }
 
 hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta, const int* lengths,
                              int B, int C, int L, bool mask_out, hipStream_t s) {
-  if (B <= 0 || C <= 0 || L <= 0 || B > 65535) return hipErrorInvalidValue;
-  dim3 grid((L + 63) / 64, B);
-  hipLaunchKernelGGL(layer_norm_kernel, grid, dim3(256), 0, s, x, y, gamma, beta, lengths, C, L, mask_out ? 1 : 0);
+  if (B <= 0 || C <= 0 || C > 1024 || L <= 0 || B > 65535) return hipErrorInvalidValue;
+  dim3 grid((L + 15) / 16, B);
+  const int m = mask_out ? 1 : 0;
+#define LN_LAUNCH(NV) hipLaunchKernelGGL(layer_norm_kernel<NV>, grid, dim3(256), 0, s, x, y, gamma, beta, lengths, C, L, m)
+  if (C <= 192) LN_LAUNCH(12);
+  else if (C <= 256) LN_LAUNCH(16);
+  else if (C <= 768) LN_LAUNCH(48);
+  else LN_LAUNCH(64);
+#undef LN_LAUNCH
   return hipGetLastError();
 }
 
@@ -57,24 +81,28 @@ hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const
 // Self-attention with windowed relative-position keys/values (reference attentions.py:226-257, banded form):
 //   s_ij = (q_i/sqrt(dk)).k_j + [|j-i|<=W] (q_i/sqrt(dk)).Ek[j-i+W];   masked (i or j beyond the length) -> -1e4
 //   p = softmax_j(s);   o_i = sum_j p_ij v_j + sum_{|j-i|<=W} p_ij Ev[j-i+W]
-// qkv is [B, 3*H*DK, L] (q rows, then k rows, then v rows).  A block handles 16 queries of one (batch, head):
-// each wave owns 4 queries, lanes run over keys, scores for the whole row stay in registers (NCH chunks of 64).
+// qkv is [B, 3*H*DK, L] (q rows, then k rows, then v rows).  A block handles 4 * QPW queries of one (batch, head),
+// QPW per wave.  K and V go through LDS in chunks of 64 keys (coalesced loads, everything in flight at once):
+//   scores:  lanes = keys;     q broadcast from LDS, the whole score row stays in registers (NCH chunks)
+//   p . v:   lanes = channels; p_ij of a key is read from its lane with v_readlane, v from LDS (row stride 65)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int ATT_DK = 96;
 constexpr int ATT_W = 4;
 
-template <int NCH>
+template <int NCH, int QPW>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, const float* __restrict__ ek,
                                                          const float* __restrict__ ev,
                                                          const int* __restrict__ lengths, float* __restrict__ out,
                                                          int H, int L) {
-  constexpr int DK = ATT_DK, W = ATT_W, NR = 2 * ATT_W + 1;
-  __shared__ __attribute__((aligned(16))) float q_s[DK][16];
-  __shared__ float qe_s[16][NR];
-  __shared__ float pw_s[16][NR];
-  __shared__ float o_s[16][DK + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+  constexpr int DK = ATT_DK, W = ATT_W, NR = 2 * ATT_W + 1, NQ = 4 * QPW, KS = 65;
+  extern __shared__ __attribute__((aligned(16))) float att_s[];
+  float* kv_s = att_s;                       // [DK][KS]   one 64-key chunk of K or V
+  float* q_s = kv_s + DK * KS;               // [DK][NQ]   (16-byte aligned: DK * KS is a multiple of 4)
+  float* qe_s = q_s + DK * NQ;               // [NQ][NR]
+  float* pw_s = qe_s + NQ * NR;              // [NQ][NR]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = blockIdx.x * NQ, h = blockIdx.y, b = blockIdx.z;
   const int C = H * DK;
   const int len = lengths ? lengths[b] : L;
   const float* qb = qkv + ((long long)b * 3 * C + h * DK) * L;
@@ -82,56 +110,64 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const float* vb = kb + (long long)C * L;
   const float inv = sqrtf((float)DK);
 
-  for (int idx = tid; idx < DK * 16; idx += 256) {
-    const int c = idx >> 4, qi = idx & 15, i = i0 + qi;
-    q_s[c][qi] = i < L ? qb[(long long)c * L + i] / inv : 0.f;
+  for (int idx = tid; idx < DK * NQ; idx += 256) {
+    const int c = idx / NQ, qi = idx % NQ, i = i0 + qi;
+    q_s[c * NQ + qi] = i < L ? qb[(long long)c * L + i] / inv : 0.f;
   }
-  if (tid < 16 * NR) pw_s[tid / NR][tid % NR] = 0.f;
+  for (int idx = tid; idx < NQ * NR; idx += 256) pw_s[idx] = 0.f;
   __syncthreads();
-  if (tid < 16 * NR) {
-    const int qi = tid / NR, r = tid % NR;
+  for (int idx = tid; idx < NQ * NR; idx += 256) {
+    const int qi = idx / NR, r = idx % NR;
     float s = 0.f;
-    for (int c = 0; c < DK; ++c) s += q_s[c][qi] * ek[r * DK + c];
-    qe_s[qi][r] = s;
+    for (int c = 0; c < DK; ++c) s += q_s[c * NQ + qi] * ek[r * DK + c];
+    qe_s[idx] = s;
   }
-  __syncthreads();
 
-  const int qw = wave * 4;
-  float sc[4][NCH];
+  auto stage = [&](const float* src, int ch) __attribute__((always_inline)) {   // kv_s[c][j] = src[c][64*ch + j]
+    for (int idx = tid; idx < DK * 64; idx += 256) {
+      const int c = idx >> 6, j = idx & 63, jj = ch * 64 + j;
+      kv_s[c * KS + j] = jj < L ? src[(long long)c * L + jj] : 0.f;
+    }
+  };
+
+  const int qw = wave * QPW;
+  float sc[QPW][NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
+    __syncthreads();                                   // previous chunk consumed (first pass: qe_s written)
+    if (ch * 64 < L) stage(kb, ch);
+    __syncthreads();
     const int j = ch * 64 + lane;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float acc[QPW];
+#pragma unroll
+    for (int n = 0; n < QPW; ++n) acc[n] = 0.f;
     if (ch * 64 < L) {
-      const bool jv = j < L;
-      const float* kp = kb + (jv ? j : 0);
-#pragma unroll 8
+#pragma unroll 4
       for (int c = 0; c < DK; ++c) {
-        const float kv = kp[(long long)c * L];
-        const float4 q4 = *reinterpret_cast<const float4*>(&q_s[c][qw]);
-        a0 += q4.x * kv;
-        a1 += q4.y * kv;
-        a2 += q4.z * kv;
-        a3 += q4.w * kv;
-      }
-      float av[4] = {a0, a1, a2, a3};
+        const float kv = kv_s[c * KS + lane];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int i = i0 + qw + n;
-        const int r = j - i + W;
-        float v = av[n];
-        if (r >= 0 && r < NR) v += qe_s[qw + n][r];
-        if (!(i < len && j < len)) v = -1e4f;
-        sc[n][ch] = jv ? v : -INFINITY;
+        for (int m = 0; m < QPW / 4; ++m) {
+          const float4 q4 = *reinterpret_cast<const float4*>(&q_s[c * NQ + qw + 4 * m]);
+          acc[4 * m + 0] += q4.x * kv;
+          acc[4 * m + 1] += q4.y * kv;
+          acc[4 * m + 2] += q4.z * kv;
+          acc[4 * m + 3] += q4.w * kv;
+        }
       }
-    } else {
+    }
 #pragma unroll
-      for (int n = 0; n < 4; ++n) sc[n][ch] = -INFINITY;
+    for (int n = 0; n < QPW; ++n) {
+      const int i = i0 + qw + n;
+      const int r = j - i + W;
+      float v = acc[n];
+      if (r >= 0 && r < NR) v += qe_s[(qw + n) * NR + r];
+      if (!(i < len && j < len)) v = -1e4f;
+      sc[n][ch] = j < L ? v : -INFINITY;
     }
   }
   // softmax over the row (all chunks, all lanes)
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
+  for (int n = 0; n < QPW; ++n) {
     float m = -INFINITY;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) m = fmaxf(m, sc[n][ch]);
@@ -153,62 +189,77 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
       const float p = sc[n][ch] * rinv;
       sc[n][ch] = p;
       const int j = ch * 64 + lane, r = j - i + W;
-      if (r >= 0 && r < NR && j < L) pw_s[qw + n][r] = p;
+      if (r >= 0 && r < NR && j < L) pw_s[(qw + n) * NR + r] = p;
     }
   }
-  // o = p . v  (per channel: lanes hold partial sums over their keys, then a wave reduction)
-  for (int c = 0; c < DK; ++c) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* vp = vb + (long long)c * L;
+  // o = p . v with lanes on channels: lane handles channel `lane` and, for lane < 32, channel 64 + lane
+  float o0[QPW], o1[QPW];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const int j = ch * 64 + lane;
-      if (ch * 64 < L) {
-        const float vv = j < L ? vp[j] : 0.f;
-        a0 += sc[0][ch] * vv;
-        a1 += sc[1][ch] * vv;
-        a2 += sc[2][ch] * vv;
-        a3 += sc[3][ch] * vv;
+  for (int n = 0; n < QPW; ++n) o0[n] = o1[n] = 0.f;
+  const int c1 = lane < DK - 64 ? 64 + lane : lane;     // lanes >= 32 repeat their first channel (result unused)
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    __syncthreads();
+    if (ch * 64 < L) stage(vb, ch);
+    __syncthreads();
+    if (ch * 64 < L) {
+      const int nj = L - ch * 64 < 64 ? L - ch * 64 : 64;
+      for (int j = 0; j < nj; ++j) {
+        const float v0 = kv_s[lane * KS + j], v1 = kv_s[c1 * KS + j];
+#pragma unroll
+        for (int n = 0; n < QPW; ++n) {
+          const float p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc[n][ch]), j));
+          o0[n] += p * v0;
+          o1[n] += p * v1;
+        }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      a0 += __shfl_xor(a0, o);
-      a1 += __shfl_xor(a1, o);
-      a2 += __shfl_xor(a2, o);
-      a3 += __shfl_xor(a3, o);
-    }
-    if (lane == 0) {
-      o_s[qw + 0][c] = a0;
-      o_s[qw + 1][c] = a1;
-      o_s[qw + 2][c] = a2;
-      o_s[qw + 3][c] = a3;
-    }
   }
-  __syncthreads();
   float* ob = out + ((long long)b * C + h * DK) * L;
-  for (int idx = tid; idx < DK * 16; idx += 256) {
-    const int c = idx >> 4, qi = idx & 15, i = i0 + qi;
-    if (i < L) {
-      float v = o_s[qi][c];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) v += pw_s[qi][r] * ev[r * DK + c];
-      ob[(long long)c * L + i] = v;
+  for (int slot = 0; slot < 2; ++slot) {
+    if (slot == 1 && lane >= DK - 64) break;
+    const int c = slot == 0 ? lane : 64 + lane;
+    float evr[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) evr[r] = ev[r * DK + c];
+#pragma unroll
+    for (int n = 0; n < QPW; ++n) {
+      const int i = i0 + qw + n;
+      if (i < L) {
+        float v = slot == 0 ? o0[n] : o1[n];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v += pw_s[(qw + n) * NR + r] * evr[r];
+        ob[(long long)c * L + i] = v;
+      }
     }
   }
+}
+
+template <int NCH, int QPW>
+static void attention_launch(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
+                             int B, int H, int L, hipStream_t s) {
+  constexpr int NQ = 4 * QPW;
+  dim3 grid((L + NQ - 1) / NQ, H, B);
+  const size_t lds = (size_t)(ATT_DK * 65 + ATT_DK * NQ + 2 * NQ * (2 * ATT_W + 1)) * sizeof(float);
+  hipLaunchKernelGGL((attention_kernel<NCH, QPW>), grid, dim3(256), lds, s, qkv, emb_k, emb_v, lengths, out, H, L);
 }
 
 hipError_t launch_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
                             int B, int H, int DK, int L, int window, hipStream_t s) {
   if (DK != ATT_DK || window != ATT_W || B <= 0 || L <= 0 || L > 2048 || B > 65535) return hipErrorInvalidValue;
-  dim3 grid((L + 15) / 16, H, B);
   const int nch = (L + 63) / 64;
-#define ATT_LAUNCH(N) hipLaunchKernelGGL(attention_kernel<N>, grid, dim3(256), 0, s, qkv, emb_k, emb_v, lengths, out, H, L)
-  if (nch <= 2) ATT_LAUNCH(2);
-  else if (nch <= 4) ATT_LAUNCH(4);
-  else if (nch <= 8) ATT_LAUNCH(8);
-  else if (nch <= 16) ATT_LAUNCH(16);
-  else ATT_LAUNCH(32);
+#define ATT_LAUNCH(N, Q) attention_launch<N, Q>(qkv, emb_k, emb_v, lengths, out, B, H, L, s)
+  // the score row lives in registers: QPW * NCH floats per lane, so longer rows take fewer queries per wave
+  if (nch <= 1) ATT_LAUNCH(1, 16);
+  else if (nch <= 2) ATT_LAUNCH(2, 16);
+  else if (nch <= 3) ATT_LAUNCH(3, 16);
+  else if (nch <= 5) ATT_LAUNCH(5, 16);
+  else if (nch <= 8) ATT_LAUNCH(8, 8);
+  else if (nch <= 12) ATT_LAUNCH(12, 8);
+  else if (nch <= 16) ATT_LAUNCH(16, 4);
+  else if (nch <= 24) ATT_LAUNCH(24, 4);
+  else ATT_LAUNCH(32, 4);
 #undef ATT_LAUNCH
   return hipGetLastError();
 }
