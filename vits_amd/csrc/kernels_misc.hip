@@ -88,6 +88,7 @@ hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const
 // ---------------------------------------------------------------------------------------------------------
 constexpr int ATT_DK = 96;
 constexpr int ATT_W = 4;
+typedef float att_f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NCH, int QPW>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, const float* __restrict__ ek,
@@ -115,11 +116,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     q_s[c * NQ + qi] = i < L ? qb[(long long)c * L + i] / inv : 0.f;
   }
   for (int idx = tid; idx < NQ * NR; idx += 256) pw_s[idx] = 0.f;
+  for (int idx = tid; idx < NR * DK; idx += 256) kv_s[idx] = ek[idx];      // relative key embeddings, via LDS
   __syncthreads();
   for (int idx = tid; idx < NQ * NR; idx += 256) {
     const int qi = idx / NR, r = idx % NR;
     float s = 0.f;
-    for (int c = 0; c < DK; ++c) s += q_s[c * NQ + qi] * ek[r * DK + c];
+#pragma unroll 8
+    for (int c = 0; c < DK; ++c) s += q_s[c * NQ + qi] * kv_s[r * DK + c];
     qe_s[idx] = s;
   }
 
@@ -138,20 +141,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     if (ch * 64 < L) stage(kb, ch);
     __syncthreads();
     const int j = ch * 64 + lane;
-    float acc[QPW];
+    att_f32x2 acc[QPW / 2];                            // pairs of queries: packed fp32 FMAs
 #pragma unroll
-    for (int n = 0; n < QPW; ++n) acc[n] = 0.f;
+    for (int n = 0; n < QPW / 2; ++n) acc[n] = att_f32x2{0.f, 0.f};
     if (ch * 64 < L) {
 #pragma unroll 4
       for (int c = 0; c < DK; ++c) {
         const float kv = kv_s[c * KS + lane];
+        const att_f32x2 kv2 = {kv, kv};
 #pragma unroll
         for (int m = 0; m < QPW / 4; ++m) {
           const float4 q4 = *reinterpret_cast<const float4*>(&q_s[c * NQ + qw + 4 * m]);
-          acc[4 * m + 0] += q4.x * kv;
-          acc[4 * m + 1] += q4.y * kv;
-          acc[4 * m + 2] += q4.z * kv;
-          acc[4 * m + 3] += q4.w * kv;
+          acc[2 * m + 0] += att_f32x2{q4.x, q4.y} * kv2;
+          acc[2 * m + 1] += att_f32x2{q4.z, q4.w} * kv2;
         }
       }
     }
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     for (int n = 0; n < QPW; ++n) {
       const int i = i0 + qw + n;
       const int r = j - i + W;
-      float v = acc[n];
+      float v = acc[n >> 1][n & 1];
       if (r >= 0 && r < NR) v += qe_s[(qw + n) * NR + r];
       if (!(i < len && j < len)) v = -1e4f;
       sc[n][ch] = j < L ? v : -INFINITY;
@@ -193,9 +195,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
   }
   // o = p . v with lanes on channels: lane handles channel `lane` and, for lane < 32, channel 64 + lane
-  float o0[QPW], o1[QPW];
+  att_f32x2 o01[QPW];                                  // (channel lane, channel 64 + lane) per query
 #pragma unroll
-  for (int n = 0; n < QPW; ++n) o0[n] = o1[n] = 0.f;
+  for (int n = 0; n < QPW; ++n) o01[n] = att_f32x2{0.f, 0.f};
   const int c1 = lane < DK - 64 ? 64 + lane : lane;     // lanes >= 32 repeat their first channel (result unused)
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -205,12 +207,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     if (ch * 64 < L) {
       const int nj = L - ch * 64 < 64 ? L - ch * 64 : 64;
       for (int j = 0; j < nj; ++j) {
-        const float v0 = kv_s[lane * KS + j], v1 = kv_s[c1 * KS + j];
+        const att_f32x2 v01 = {kv_s[lane * KS + j], kv_s[c1 * KS + j]};
 #pragma unroll
         for (int n = 0; n < QPW; ++n) {
           const float p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc[n][ch]), j));
-          o0[n] += p * v0;
-          o1[n] += p * v1;
+          o01[n] += att_f32x2{p, p} * v01;
         }
       }
     }
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     for (int n = 0; n < QPW; ++n) {
       const int i = i0 + qw + n;
       if (i < L) {
-        float v = slot == 0 ? o0[n] : o1[n];
+        float v = o01[n][slot];
 #pragma unroll
         for (int r = 0; r < NR; ++r) v += pw_s[(qw + n) * NR + r] * evr[r];
         ob[(long long)c * L + i] = v;
@@ -383,10 +384,118 @@ __global__ __launch_bounds__(256) void conv_to1_kernel(const float* __restrict__
   out[(long long)b * L + t] = acc;
 }
 
+// Short sequences: block = 16 time steps x 16 channel groups (channels g, g + 16, ...), partial sums reduced with
+// shuffles across the four groups of a wave and through LDS across waves: the reduction over up to 768 channels is
+// no longer one thread's serial chain.
+__global__ __launch_bounds__(256) void conv_to1_split_kernel(const float* __restrict__ x, long long x_bs, int x_cs,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              const int* __restrict__ lengths, int C, int K, int L,
+                                                              int flags, float in_scale, float in_slope, int tanh_out,
+                                                              int mask_out) {
+  __shared__ float red[4][16];
+  const int tl = threadIdx.x & 15, g = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t = blockIdx.x * 16 + tl;
+  const int len = lengths ? lengths[b] : 0x7fffffff;
+  const int pad = (K - 1) / 2;
+  const float* xb = x + (long long)b * x_bs;
+  float acc = 0.f;
+  if (t < L) {
+#pragma unroll 4
+    for (int c = g; c < C; c += 16) {
+      const float* xr = xb + (long long)c * x_cs;
+      for (int k = 0; k < K; ++k) {
+        const int tt = t + k - pad;
+        bool ok = tt >= 0 && tt < L;
+        if (flags & F_IN_MASK) ok = ok && tt < len;
+        float v = ok ? xr[tt] * in_scale : 0.f;
+        if (flags & F_IN_LRELU) v = v > 0.f ? v : v * in_slope;
+        acc += w[c * K + k] * v;
+      }
+    }
+  }
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  if ((threadIdx.x & 63) < 16) red[wave][tl] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16 && t < L) {
+    acc = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+    if (bias) acc += bias[0];
+    if (tanh_out) acc = tanhf(acc);
+    if (mask_out && t >= len) acc = 0.f;
+    out[(long long)b * L + t] = acc;
+  }
+}
+
+// Long sequences with 16-byte aligned rows: a thread produces four consecutive outputs from float4 loads of the row
+// segment [t - 4, t + 8) (K <= 9), so a loaded value serves up to K taps from registers.
+template <int K>
+__global__ __launch_bounds__(256) void conv_to1_vec4_kernel(const float* __restrict__ x, long long x_bs, int x_cs,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             const int* __restrict__ lengths, int C, int L,
+                                                             int flags, float in_scale, float in_slope, int tanh_out,
+                                                             int mask_out) {
+  const int b = blockIdx.y;
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= L) return;
+  const int len = lengths ? lengths[b] : 0x7fffffff;
+  constexpr int pad = (K - 1) / 2;
+  const float* xb = x + (long long)b * x_bs;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < C; ++c) {
+    const float* xr = xb + (long long)c * x_cs;
+    float v[12];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int tq = t - 4 + 4 * q;
+      float4 f = {0.f, 0.f, 0.f, 0.f};
+      if (tq >= 0 && tq < L) f = *reinterpret_cast<const float4*>(xr + tq);
+      v[4 * q + 0] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+      const int tt = t - 4 + e;
+      float u = v[e] * in_scale;
+      if ((flags & F_IN_MASK) && tt >= len) u = 0.f;
+      if (flags & F_IN_LRELU) u = u > 0.f ? u : u * in_slope;
+      v[e] = u;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float wk = w[c * K + k];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[o] += wk * v[4 + o + k - pad];   // input position t + o + k - pad
+    }
+  }
+  float4 r;
+  float* rp = &r.x;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    float a = acc[o];
+    if (bias) a += bias[0];
+    if (tanh_out) a = tanhf(a);
+    if (mask_out && t + o >= len) a = 0.f;
+    rp[o] = a;
+  }
+  *reinterpret_cast<float4*>(out + (long long)b * L + t) = r;
+}
+
 hipError_t launch_conv_to1(const float* x, long long x_bs, int x_cs, const float* w, const float* bias, float* out,
                            const int* lengths, int B, int C, int K, int L, int flags, float in_scale, float in_slope,
                            bool tanh_out, bool mask_out, hipStream_t s) {
   if (B <= 0 || L <= 0 || B > 65535) return hipErrorInvalidValue;
+  if (L <= 2048) {
+    hipLaunchKernelGGL(conv_to1_split_kernel, dim3((L + 15) / 16, B), dim3(256), 0, s, x, x_bs, x_cs, w, bias, out,
+                       lengths, C, K, L, flags, in_scale, in_slope, tanh_out ? 1 : 0, mask_out ? 1 : 0);
+    return hipGetLastError();
+  }
+  if (K == 7 && L % 4 == 0 && x_cs % 4 == 0 && x_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    hipLaunchKernelGGL(conv_to1_vec4_kernel<7>, dim3((L / 4 + 255) / 256, B), dim3(256), 0, s, x, x_bs, x_cs, w, bias, out,
+                       lengths, C, L, flags, in_scale, in_slope, tanh_out ? 1 : 0, mask_out ? 1 : 0);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(conv_to1_kernel, dim3((L + 255) / 256, B), dim3(256), 0, s, x, x_bs, x_cs, w, bias, out, lengths,
                      C, K, L, flags, in_scale, in_slope, tanh_out ? 1 : 0, mask_out ? 1 : 0);
   return hipGetLastError();
