@@ -167,13 +167,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
     if (mt_ok[0]) {
       const int hrows = a.M >> 1;
       const int rowu = mt[0] * 32;
-      float ba[16], bs[16];
+      float ba[16], bs[16];                // whole-table branches: the loads of a table go out back to back
+      const int row0 = rowu + 4 * par;
+      if (a.bias) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rowu + (r & 3) + 8 * (r >> 2) + 4 * par;
-        ba[r] = a.bias ? a.bias[row] : 0.f;
-        bs[r] = a.bias ? a.bias[row + hrows] : 0.f;
-        if (cbias_b) { ba[r] += cbias_b[row]; bs[r] += cbias_b[row + hrows]; }
+        for (int r = 0; r < 16; ++r) {
+          ba[r] = a.bias[row0 + (r & 3) + 8 * (r >> 2)];
+          bs[r] = a.bias[row0 + (r & 3) + 8 * (r >> 2) + hrows];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ba[r] = bs[r] = 0.f;
+      }
+      if (cbias_b) {
+        float ca[16], cs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ca[r] = cbias_b[row0 + (r & 3) + 8 * (r >> 2)];
+          cs[r] = cbias_b[row0 + (r & 3) + 8 * (r >> 2) + hrows];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ba[r] += ca[r];
+          bs[r] += cs[r];
+        }
       }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
@@ -183,8 +200,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float va = acc[0][j][r] + ba[r], vs = acc[WM - 1][j][r] + bs[r];
-          (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] =
-              tanhf(va) * (1.f / (1.f + expf(-vs)));
+          // tanh(a) * sigmoid(s) on the hardware exp: tanh(a) = 1 - 2 / (1 + e^(2a)) (saturates cleanly at +-1),
+          // absolute error ~1e-7 against libm
+          const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * va));
+          const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-vs));
+          (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = th * sg;
         }
       }
     }
@@ -1253,14 +1273,19 @@ template <int MODE>
 static bool try_launch_ks(ConvArgs& a, hipStream_t stream, hipError_t& err) {
   if (!ks_enabled() || a.M % 64 != 0 || a.Cin < 64 || a.in_cbias) return false;
   const int n32 = (a.L + 31) / 32;
-  int wn = 1, best = n32;                                   // fewest padded 32-column tiles, then the widest tile
-  for (int c = 2; c <= 3; ++c) {
-    const int padded = (n32 + c - 1) / c * c;
-    if (padded <= best) { best = padded; wn = c; }
-  }
   const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + 1) / 2;
-  const long long blocks = (long long)((n32 + wn - 1) / wn) * units * a.B;
-  if (blocks > 2LL * device_cu_count()) return false;
+  const int cus = device_cu_count();
+  // Tile width: the launch is latency-bound, so what counts is how many block "rounds" the chip needs (blocks of
+  // width 1 and 2 fit two to a CU, width 3 one) times the length of a block's chain (a fixed part + the tile width).
+  int wn = 0;
+  long long best = 0, best_blocks = 0;
+  for (int c = 1; c <= 3; ++c) {
+    const long long blocks = (long long)((n32 + c - 1) / c) * units * a.B;
+    const long long slots = (long long)cus * (c <= 2 ? 2 : 1);
+    const long long cost = ((blocks + slots - 1) / slots) * (2 + c);
+    if (wn == 0 || cost < best) { best = cost; wn = c; best_blocks = blocks; }
+  }
+  if (best_blocks > 2LL * cus) return false;
   err = wn == 1 ? launch_b3ks<1, MODE>(a, stream) : wn == 2 ? launch_b3ks<2, MODE>(a, stream) : launch_b3ks<3, MODE>(a, stream);
   return true;
 }

@@ -111,9 +111,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const float* vb = kb + (long long)C * L;
   const float inv = sqrtf((float)DK);
 
-  for (int idx = tid; idx < DK * NQ; idx += 256) {
-    const int c = idx / NQ, qi = idx % NQ, i = i0 + qi;
-    q_s[c * NQ + qi] = i < L ? qb[(long long)c * L + i] / inv : 0.f;
+  {                                                  // all loads of the staging pass are issued before the first LDS write
+    constexpr int NU = DK * NQ / 256;
+    float tmp[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int idx = tid + 256 * u, c = idx / NQ, i = i0 + idx % NQ;
+      tmp[u] = qb[(long long)c * L + (i < L ? i : L - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int idx = tid + 256 * u, i = i0 + idx % NQ;
+      q_s[idx] = i < L ? tmp[u] / inv : 0.f;
+    }
   }
   for (int idx = tid; idx < NQ * NR; idx += 256) pw_s[idx] = 0.f;
   for (int idx = tid; idx < NR * DK; idx += 256) kv_s[idx] = ek[idx];      // relative key embeddings, via LDS
@@ -127,10 +137,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 
   auto stage = [&](const float* src, int ch) __attribute__((always_inline)) {   // kv_s[c][j] = src[c][64*ch + j]
-    for (int idx = tid; idx < DK * 64; idx += 256) {
-      const int c = idx >> 6, j = idx & 63, jj = ch * 64 + j;
-      kv_s[c * KS + j] = jj < L ? src[(long long)c * L + jj] : 0.f;
-    }
+    constexpr int NU = DK * 64 / 256;
+    float tmp[NU];
+    const int j = tid & 63, jj = ch * 64 + j;
+    const float* sp = src + (jj < L ? jj : L - 1);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) tmp[u] = sp[(long long)(4 * u + (tid >> 6)) * L];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) kv_s[(4 * u + (tid >> 6)) * KS + j] = jj < L ? tmp[u] : 0.f;
   };
 
   const int qw = wave * QPW;
