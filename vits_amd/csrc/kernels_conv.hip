@@ -587,27 +587,22 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < WN; ++j) B[p][c][j] = xq[p * 2 * ncols + boff[c] + j * 32];
       ++it;
-      const bool more = it < n_it;
-      const long long nxt = (long long)it * it_stride;
+      // the reloads are unconditional (the last tap re-reads its own fragments): straight-line code lets the
+      // compiler wait for exactly the plane it needs instead of draining every outstanding load at a join
+      const long long nxt = (long long)(it < n_it ? it : n_it - 1) * it_stride;
       // smallest terms first; each weight plane is reloaded for the next tap right after its last use
       mma(A[2], B[0]);                                   // l * h
-      if (more) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) A[2][i] = wp[i][nxt + 128];
-      }
+      for (int i = 0; i < WM; ++i) A[2][i] = wp[i][nxt + 128];
       mma(A[1], B[1]);                                   // m * m
       mma(A[1], B[0]);                                   // m * h
-      if (more) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) A[1][i] = wp[i][nxt + 64];
-      }
+      for (int i = 0; i < WM; ++i) A[1][i] = wp[i][nxt + 64];
       mma(A[0], B[2]);                                   // h * l
       mma(A[0], B[1]);                                   // h * m
       mma(A[0], B[0]);                                   // h * h
-      if (more) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) A[0][i] = wp[i][nxt];
-      }
+      for (int i = 0; i < WM; ++i) A[0][i] = wp[i][nxt];
 #pragma unroll
       for (int c = 0; c < NB; ++c) boff[c] += a.tstep[c];
     }
@@ -1285,7 +1280,8 @@ static bool try_launch_ks(ConvArgs& a, hipStream_t stream, hipError_t& err) {
     const long long cost = ((blocks + slots - 1) / slots) * (2 + c);
     if (wn == 0 || cost < best) { best = cost; wn = c; best_blocks = blocks; }
   }
-  if (best_blocks > 2LL * cus) return false;
+  // beyond two blocks per CU the one-role kernel wins, except for deep reductions (>= 256 channels, >= 5 taps)
+  if (best_blocks > 2LL * cus && !(a.Cin >= 256 && a.K >= 5)) return false;
   err = wn == 1 ? launch_b3ks<1, MODE>(a, stream) : wn == 2 ? launch_b3ks<2, MODE>(a, stream) : launch_b3ks<3, MODE>(a, stream);
   return true;
 }
