@@ -57,6 +57,17 @@ def algorithmic_flops(phoneme_counts, frame_counts, predicted_duration=False):
     return sum(837861376 * t + 3072 * t * t + per_p * p + 7680 * p * p for p, t in zip(phoneme_counts, frame_counts))
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` (2 * FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes over
+    this benchmark's command (profiles/r01_pmc_traffic.json: the command, the gfx950 FETCH_SIZE correction and its
+    check are recorded there); None when no pass covers the kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(sample_utts=4, runs=2):
     """Time the CPU oracle on a bounded sample: `sample_utts` utterances of the benchmark workload."""
     from oracle.mvts_oracle import OracleSynthesizer
@@ -149,7 +160,7 @@ def main():
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         peak = PEAK_FP32_MFMA_TFLOPS if dom["name"].startswith("conv_mfma_kernel") else PEAK_BF16X3_TFLOPS
         roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(achieved, 3), peak=round(peak, 1),
-                        unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
+                        unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=pmc_traffic(dom["name"]),
                         launches_per_step=dom["count"] // args.steps,
                         avg_launch_us=round(dom["ms"] * 1e3 / dom["count"], 2),
                         flops_per_launch=round(dom["flops"] / dom["count"]),
