@@ -96,7 +96,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // All loads of a tile are issued before its first store: out may alias res (in-place residual update), so a
 // per-element load -> store sequence would serialise 16 memory round trips.
 // ---------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int MODE>
+template <int WM, int WN, int MODE, bool RES_ALL = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[WM][WN], const int (&mt)[WM],
                                               const bool (&mt_ok)[WM], int wn, int par, int l31, int t0, int b,
                                               int len_b) {
@@ -104,22 +104,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
   float* out_b = a.out + (long long)b * a.out_bs;
   if constexpr (MODE == MODE_PLAIN) {
     const float* res_b = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+    // Residual loads go out before the first store of the rows they cover (out may alias res element for element,
+    // which this order keeps correct).  RES_ALL: the whole wave tile at once (one memory round trip, WM * WN * 16
+    // registers); otherwise one 32-row block at a time.
+    constexpr int RI = RES_ALL ? WM : 1;
+    float rv[RI][WN][16];
+    auto load_res = [&](int i, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + (wn * WN + j) * 32 + l31;
+        const unsigned lo_res = (unsigned)(4 * par * a.res_cs + (t < a.L ? t : a.L - 1));
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rv[slot][j][r] = (res_b + (long long)(mt[i] * 32 + (r & 3) + 8 * (r >> 2)) * a.res_cs)[lo_res];
+      }
+    };
+    if constexpr (RES_ALL) {
+      if (a.flags & (F_RES | F_RES_SUB)) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) load_res(i, i);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       if (!mt_ok[i]) continue;
       const int rowu = mt[i] * 32;
-      // the residual loads of all WN accumulator tiles of this row block go out before its first store: one memory
-      // round trip per row block (out may alias res element for element, which this order keeps correct)
-      float rv[WN][16];
-      if (a.flags & (F_RES | F_RES_SUB)) {
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const int t = t0 + (wn * WN + j) * 32 + l31;
-          const unsigned lo_res = (unsigned)(4 * par * a.res_cs + (t < a.L ? t : a.L - 1));
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            rv[j][r] = (res_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.res_cs)[lo_res];
-        }
+      const int ri = RES_ALL ? i : 0;
+      if constexpr (!RES_ALL) {
+        if (a.flags & (F_RES | F_RES_SUB)) load_res(i, 0);
       }
       float bz[16];                        // whole-array branches: the 16 loads of a table are issued back to back
       const int row0 = rowu + 4 * par;
@@ -154,8 +166,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
             float v = acc[i][j][r] + bz[r];
             if (a.flags & F_RELU) v = fmaxf(v, 0.f);
             if (a.flags & F_MASK_PRE) v *= m;
-            if (a.flags & F_RES) v += rv[j][r];
-            if (a.flags & F_RES_SUB) v = rv[j][r] - v;
+            if (a.flags & F_RES) v += rv[ri][j][r];
+            if (a.flags & F_RES_SUB) v = rv[ri][j][r] - v;
             if (a.flags & F_ACCUM) v += ov[r];
             if (a.flags & F_MASK_POST) v *= m;
             (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = v;
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
 
-  conv_epilogue<WM, WN, MODE>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+  conv_epilogue<WM, WN, MODE, true>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -573,38 +585,49 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
   };
 
   const int colbase = wn * WN * 32 + l31 + par * ncols - a.min_off;
+  uint4 B[3][NB][WN];             // planes h, m, l of the current tap
+  auto ldb = [&](int p, const int (&off)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) B[p][c][j] = xq[p * 2 * ncols + off[c] + j * 32];
+  };
+  // Every operand plane is refetched for the next tap right after its last use in this one (weights from L2,
+  // activations from LDS), and the order of the six products puts the h planes' uses first: the refetches have two
+  // to five MFMA groups to land, with no second register set.  The reloads are unconditional (a chunk's last tap
+  // re-reads its own activation fragments, the last tap of all its own weights), so the code stays straight-line and
+  // the compiler waits for exactly the plane it needs.
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     if (chunk + 1 < nchunks) load_chunk(chunk + 1);
     int boff[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) boff[c] = colbase + a.toff0[c];
+    ldb(0, boff);
+    ldb(1, boff);
+    ldb(2, boff);
     for (int k = 0; k < a.K; ++k) {
-      uint4 B[3][NB][WN];
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
-#pragma unroll
-          for (int j = 0; j < WN; ++j) B[p][c][j] = xq[p * 2 * ncols + boff[c] + j * 32];
       ++it;
-      // the reloads are unconditional (the last tap re-reads its own fragments): straight-line code lets the
-      // compiler wait for exactly the plane it needs instead of draining every outstanding load at a join
       const long long nxt = (long long)(it < n_it ? it : n_it - 1) * it_stride;
-      // smallest terms first; each weight plane is reloaded for the next tap right after its last use
-      mma(A[2], B[0]);                                   // l * h
+      int boffn[NB];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) A[2][i] = wp[i][nxt + 128];
-      mma(A[1], B[1]);                                   // m * m
-      mma(A[1], B[0]);                                   // m * h
-#pragma unroll
-      for (int i = 0; i < WM; ++i) A[1][i] = wp[i][nxt + 64];
+      for (int c = 0; c < NB; ++c) boffn[c] = k + 1 < a.K ? boff[c] + a.tstep[c] : boff[c];
       mma(A[0], B[2]);                                   // h * l
+      ldb(2, boffn);
       mma(A[0], B[1]);                                   // h * m
       mma(A[0], B[0]);                                   // h * h
 #pragma unroll
       for (int i = 0; i < WM; ++i) A[0][i] = wp[i][nxt];
+      mma(A[1], B[1]);                                   // m * m
+      ldb(1, boffn);
+      mma(A[1], B[0]);                                   // m * h
 #pragma unroll
-      for (int c = 0; c < NB; ++c) boff[c] += a.tstep[c];
+      for (int i = 0; i < WM; ++i) A[1][i] = wp[i][nxt + 64];
+      mma(A[2], B[0]);                                   // l * h
+#pragma unroll
+      for (int i = 0; i < WM; ++i) A[2][i] = wp[i][nxt + 128];
+      ldb(0, boffn);
+#pragma unroll
+      for (int c = 0; c < NB; ++c) boff[c] = boffn[c];
     }
     if (chunk + 1 < nchunks) {
       __syncthreads();
@@ -613,31 +636,14 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
     }
   }
 
-  conv_epilogue<WM, WN, MODE>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+  conv_epilogue<WM, WN, MODE, true>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// PREC_BF16X3, wave-specialised persistent kernel (MODE_PLAIN / MODE_GATE, 64-row wave tiles).
-//
-// vmcnt retires in order, so a wave that mixes the HBM loads of the next activation chunk with the L2 loads of its
-// next weight fragments waits a full HBM round trip in front of every chunk's second tap.  Here the two streams
-// belong to different waves of one 384-thread block:
-//   waves 4..5  producers: stream activation chunks HBM -> registers (two chunks in flight) -> prologue -> bf16x3
-//               split -> LDS ring of two stages.  All VALU work of the staging runs beside the other waves' MFMAs.
-//   waves 0..3  consumers: per tap, 6 weight fragments from L2 and 6 activation fragments from LDS feed 24 MFMAs;
-//               the h and m planes of both operands are double-buffered in registers one tap ahead, the l planes are
-//               reloaded right after their only use.
-// One s_barrier per channel chunk hands a filled stage to the consumers and a drained one back.  A block walks the
-// tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the producers are always one chunk ahead, so the first chunk of
-// the next tile is staged while the consumers run the epilogue of the current one.
-// Both roles execute exactly 1 + (tiles of this block) * (Cin / 16) barriers.
+// helpers shared by the bf16x3 kernels below
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-constexpr int WS_PRODUCER_WAVES = 2;
-#ifndef WS_DBG
-#define WS_DBG 0
-#endif
 
 // (v0, v1) -> packed bf16 pairs h, m, l with v = h + m + l exactly (low half = v0)
 __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
@@ -651,270 +657,6 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, uns
 
 template <int V>
 struct IntC { static constexpr int value = V; };
-
-template <int WM, int WN, int WGM, int WGN, int MODE>
-__global__ __launch_bounds__(256 + 64 * WS_PRODUCER_WAVES, 3) void conv_b3ws_kernel(const ConvArgs a, const int tiles_n,
-                                                                                 const int tiles_m, const int ntiles) {
-  constexpr int BN = 32 * WN * WGN;
-  constexpr int NPT = 64 * WS_PRODUCER_WAVES;
-  constexpr int NPASS = (2 * ((BN + MAX_HALO + 63) / 64 * 64) + NPT - 1) / NPT;   // (column, half) items per thread
-  static_assert(WGM * WGN == 4, "four consumer waves per block");
-  static_assert(MODE == MODE_PLAIN || MODE == MODE_GATE, "one row class only");
-  static_assert(WM == 2, "64-row wave tiles");
-
-  extern __shared__ __attribute__((aligned(16))) uint4 xq[];    // [2 stages][3 planes][2 halves][ncols] of 8 bf16
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ncols = a.rs;
-  const int stage_sz = 6 * ncols;
-  const int nchunks = a.Cin / 16;
-  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int G = my_tiles * nchunks;                             // chunks this block stages and multiplies
-  const int mtb = blockIdx.x % tiles_m;                         // gridDim.x is a multiple of tiles_m
-
-  if (wave >= 4) {
-    // ------------------------------------------------ producers ------------------------------------------------
-    // Items are (column, channel-half) pairs; columns are padded to a multiple of 64 so that a wave's 64 items
-    // share their half: the 8 row bases of a pass are scalars and one per-lane column offset serves all 8 loads.
-    // issue() is branch-free and always requests NPASS * 8 loads (past the block's last chunk it re-reads the
-    // first one), so the wait in front of a conversion is an exact vmcnt that leaves the newer chunk in flight.
-    const int lane = tid & 63;
-    const int wbase = (wave - 4) * 64;
-    const int ncols_pad = (ncols + 63) & ~63;
-    float R0[NPASS][8], R1[NPASS][8];
-    int t0s = 0, b0s = 0, t1s = 0, b1s = 0;                     // tile start and batch of the data in R0 / R1
-    int ltile = blockIdx.x, lchunk = 0, gl = 0;                 // next chunk to request
-
-    auto issue = [&](float (&R)[NPASS][8], int& ts, int& bs) {
-      const bool live = gl < G;
-      const int r = (live ? ltile : (int)blockIdx.x) / tiles_m;
-      const int ch = live ? lchunk : 0;
-      const int nt = r % tiles_n;
-      bs = r / tiles_n;
-      ts = nt * BN + a.min_off;
-      const float* xb = a.x + (long long)bs * a.x_bs + (long long)ch * 16 * a.x_cs;
-#pragma unroll
-      for (int q = 0; q < NPASS; ++q) {
-        const int item0 = q * NPT + wbase;                      // wave-uniform
-        const int half = item0 >= ncols_pad ? 1 : 0;
-        const int col = item0 - half * ncols_pad + lane;
-        const int t = ts + col;
-        const unsigned toff = (col < ncols && t >= 0 && t < a.L) ? (unsigned)t : 0u;
-        const float* xr = xb + (long long)half * 8 * a.x_cs;
-#pragma unroll
-#if (WS_DBG & 16)
-        for (int j = 0; j < 8; ++j) R[q][j] = (float)(toff + j);
-        (void)xr;
-#else
-        for (int j = 0; j < 8; ++j) R[q][j] = (xr + (long long)j * a.x_cs)[toff];     // raw: convert() zeroes
-#endif
-      }
-      if (++lchunk == nchunks) {
-        lchunk = 0;
-        ltile += gridDim.x;
-      }
-      ++gl;
-    };
-    auto convert = [&](float (&R)[NPASS][8], int ts, int bs, int stage) {
-      const int len_b = (a.flags & F_IN_MASK) && a.lengths ? a.lengths[bs] : 0x7fffffff;
-      uint4* dst = xq + stage * stage_sz;
-#pragma unroll
-      for (int q = 0; q < NPASS; ++q) {
-        const int item0 = q * NPT + wbase;
-        const int half = item0 >= ncols_pad ? 1 : 0;
-        const int col = item0 - half * ncols_pad + lane;        // >= ncols for the padding and for surplus passes
-        const int t = ts + col;
-        const bool ok = t >= 0 && t < a.L && t < len_b;
-        unsigned ph[4], pm[4], pl[4];
-#pragma unroll
-        for (int c2 = 0; c2 < 4; ++c2) {
-          float v[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            float x = R[q][2 * c2 + u] * a.in_scale;
-            if (a.flags & F_IN_LRELU) x = fmaxf(x, x * a.in_slope);
-            v[u] = ok ? x : 0.f;
-          }
-          split3_pair(v[0], v[1], ph[c2], pm[c2], pl[c2]);
-        }
-        if (col < ncols) {
-          dst[(0 * 2 + half) * ncols + col] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-          dst[(1 * 2 + half) * ncols + col] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-          dst[(2 * 2 + half) * ncols + col] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-        }
-      }
-    };
-
-    // G is even (the launcher checks Cin / 16).  Chunk g + 1 is converted while the consumers multiply chunk g.
-    issue(R0, t0s, b0s);
-    issue(R1, t1s, b1s);
-    convert(R0, t0s, b0s, 0);
-    issue(R0, t0s, b0s);
-    __syncthreads();                                            // stage 0 holds chunk 0
-    for (int g = 0; g < G; g += 2) {
-#if !(WS_DBG & 4)
-      convert(R1, t1s, b1s, 1);
-#endif
-      issue(R1, t1s, b1s);
-      __syncthreads();                                          // end of chunk g
-#if !(WS_DBG & 4)
-      if (g + 2 < G) convert(R0, t0s, b0s, 0);
-#endif
-      issue(R0, t0s, b0s);
-      __syncthreads();                                          // end of chunk g + 1
-    }
-    return;
-  }
-
-  // -------------------------------------------------- consumers --------------------------------------------------
-  const int lane = tid & 63, par = lane >> 5, l31 = lane & 31;
-  const int wm = wave / WGN, wn = wave % WGN;
-  int mt[WM];
-  bool mt_ok[WM];
-  if constexpr (MODE == MODE_GATE) {
-    const int half = a.mt_total >> 1;
-    const int p = mtb * WGM + wm;
-    mt_ok[0] = mt_ok[WM - 1] = p < half;
-    mt[0] = p < half ? p : half - 1;
-    mt[WM - 1] = mt[0] + half;
-  } else {
-    const int base = (mtb * WGM + wm) * WM;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      mt_ok[i] = base + i < a.mt_total;
-      mt[i] = mt_ok[i] ? base + i : a.mt_total - 1;
-    }
-  }
-
-  f32x16 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // weight fragments: index (((chunk*K + tap) * mt_total + mt) * 3 + plane) * 64 + lane, in 16-byte units
-  const uint4* w16 = reinterpret_cast<const uint4*>(a.w);
-  unsigned wofs[WM];
-#pragma unroll
-  for (int i = 0; i < WM; ++i) wofs[i] = (unsigned)(mt[i] * 192 + lane);
-  const long long it_stride = (long long)a.mt_total * 192;
-  const int n_it = nchunks * a.K;
-  const int colbase = wn * WN * 32 + l31 + par * ncols - a.min_off;
-  int it = 0, k = 0, sb = 0, boff = colbase + a.toff0[0];
-  int tile = blockIdx.x;
-
-  uint4 Ah[2][WM], Am[2][WM], Al[WM], Bh[2][WN], Bm[2][WN], Bl[WN];
-  auto lda = [&](uint4 (&d)[WM], long long base, int plane) {
-#pragma unroll
-    for (int i = 0; i < WM; ++i) d[i] = (w16 + base + plane * 64)[wofs[i]];
-  };
-  auto ldb = [&](uint4 (&d)[WN], int plane, int off) {
-#pragma unroll
-    for (int j = 0; j < WN; ++j) d[j] = xq[sb + plane * 2 * ncols + off + j * 32];
-  };
-  auto mma = [&](const uint4 (&af)[WM], const uint4 (&bf)[WN]) {
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-      for (int j = 0; j < WN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                            __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
-  };
-
-  lda(Ah[0], 0, 0);
-  lda(Am[0], 0, 1);
-  lda(Al, 0, 2);
-  __syncthreads();                                              // stage 0 holds chunk 0
-  ldb(Bh[0], 0, boff);
-  ldb(Bm[0], 1, boff);
-  ldb(Bl, 2, boff);
-
-  // One tap: the sched_barriers pin the issue order (prefetches first), which the scheduler would otherwise sink
-  // below the MFMAs they are meant to overlap.
-  auto step = [&](auto P, bool last) {
-    constexpr int c = decltype(P)::value, n = c ^ 1;
-    const int itn = it + 1 == n_it ? 0 : it + 1;                // wraps to the first tap of the next tile
-    const long long wb = (long long)itn * it_stride;
-    const int boffn = last ? boff : boff + a.tstep[0];          // on a chunk's last tap: a harmless re-read
-#if !(WS_DBG & 1)
-    lda(Ah[n], wb, 0);
-    lda(Am[n], wb, 1);
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    mma(Ah[c], Bl);                                             // h * l
-    __builtin_amdgcn_sched_barrier(0);
-#if !(WS_DBG & 2)
-    ldb(Bh[n], 0, boffn);
-    ldb(Bm[n], 1, boffn);
-    ldb(Bl, 2, boffn);
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    mma(Al, Bh[c]);                                             // l * h
-    __builtin_amdgcn_sched_barrier(0);
-#if !(WS_DBG & 1)
-    lda(Al, wb, 2);
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    mma(Am[c], Bm[c]);                                          // m * m
-    mma(Ah[c], Bm[c]);                                          // h * m
-    mma(Am[c], Bh[c]);                                          // m * h
-    mma(Ah[c], Bh[c]);                                          // h * h
-    __builtin_amdgcn_sched_barrier(0);
-    it = itn;
-    boff = boffn;
-  };
-  auto reload_b = [&](auto P) {
-    constexpr int c = decltype(P)::value;
-    ldb(Bh[c], 0, boff);
-    ldb(Bm[c], 1, boff);
-    ldb(Bl, 2, boff);
-  };
-
-  // n_it is even (the launcher checks), so a tile starts on register set 0 and can only end after a set-1 tap.
-  const int S = my_tiles * n_it;
-  for (int s = 0; s < S; s += 2) {
-    bool last = k == a.K - 1;                                   // last tap of the chunk
-    step(IntC<0>{}, last);
-    ++k;
-    if (last) {
-      k = 0;
-      sb = sb ? 0 : stage_sz;
-      boff = colbase + a.toff0[0];
-      __syncthreads();                                          // end of this chunk; the other stage is filled
-      reload_b(IntC<1>{});
-    }
-    last = k == a.K - 1;
-    step(IntC<1>{}, last);
-    ++k;
-    if (last) {
-      k = 0;
-      sb = sb ? 0 : stage_sz;
-      boff = colbase + a.toff0[0];
-      __syncthreads();
-      if (it == 0) {                                            // the tile is complete
-        const int r = tile / tiles_m;
-        const int nt = r % tiles_n, b = r / tiles_n;
-        const int len_b = a.lengths ? a.lengths[b] : 0x7fffffff;
-#if (WS_DBG & 8)
-        if (acc[0][0][0] == 12345.678f)
-#endif
-        conv_epilogue<WM, WN, MODE>(a, acc, mt, mt_ok, wn, par, l31, nt * BN, b, len_b);
-#if !(WS_DBG & 8)
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r2 = 0; r2 < 16; ++r2) acc[i][j][r2] = 0.f;
-#endif
-        tile += gridDim.x;
-      }
-      reload_b(IntC<0>{});
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // launchers
@@ -1205,38 +947,6 @@ static int device_cu_count() {
   return n;
 }
 
-// VITS_CONV_WS=1 routes the eligible bf16x3 convs to the wave-specialised kernel (experimental: slower than the
-// one-role kernel on the generator's shapes as measured so far, kept for A/B measurements).
-static bool ws_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("VITS_CONV_WS");
-    return e && e[0] == '1';
-  }();
-  return on;
-}
-
-template <int WM, int WN, int WGM, int WGN, int MODE>
-static hipError_t launch_b3ws(ConvArgs& a, hipStream_t stream) {
-  constexpr int BN = 32 * WN * WGN;
-  a.width = BN + (a.width);
-  a.rs = a.width;
-  const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + WM - 1) / WM;
-  const int tiles_m = (units + WGM - 1) / WGM, tiles_n = (a.L + BN - 1) / BN;
-  const long long nt = (long long)a.B * tiles_n * tiles_m;
-  if (nt > 0x7fffffffLL) return hipErrorInvalidValue;
-  const int ntiles = (int)nt;
-  int grid = ntiles < 2 * device_cu_count() ? ntiles : 2 * device_cu_count();   // two resident blocks per CU
-  grid -= grid % tiles_m;                                                       // keeps a block on one row block
-  if (grid < tiles_m) grid = tiles_m;
-  const size_t lds = (size_t)2 * 6 * a.rs * sizeof(uint4);
-  char name[96];
-  snprintf(name, sizeof name, "conv_b3ws_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
-  return timed_launch(name, a, stream, [&] {
-    hipLaunchKernelGGL((conv_b3ws_kernel<WM, WN, WGM, WGN, MODE>), dim3(grid), dim3(256 + 64 * WS_PRODUCER_WAVES), lds,
-                       stream, a, tiles_n, tiles_m, ntiles);
-  });
-}
-
 // VITS_CONV_KS=0 keeps short sequences on the one-role kernel (for A/B measurements).
 static bool ks_enabled() {
   static const bool on = [] {
@@ -1288,12 +998,6 @@ static bool try_launch_ks(ConvArgs& a, hipStream_t stream, hipError_t& err) {
 
 template <int WM, int WN, int WGM, int WGN, int MODE>
 static hipError_t launch_cfg(ConvArgs& a, int prec, hipStream_t stream) {
-  if constexpr (WM == 2 && WN == 2 && (MODE == MODE_PLAIN || MODE == MODE_GATE)) {
-    // the wave-specialised kernel alternates two register sets per tap and needs an even tap count per tile;
-    // it has no per-channel input bias
-    if (prec == PREC_BF16X3 && ws_enabled() && (a.Cin / 16) % 2 == 0 && a.K % 2 == 1 && !a.in_cbias)
-      return launch_b3ws<WM, WN, WGM, WGN, MODE>(a, stream);
-  }
   if (prec == PREC_BF16X3) return launch_b3<WM, WN, WGM, WGN, MODE>(a, stream);
   // dwordx4 staging needs 16-byte aligned rows and whole groups of four time steps
   const bool vec = a.L % 4 == 0 && a.x_cs % 4 == 0 && a.x_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
