@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--frames", type=int, default=258, help="frames per utterance (C2: 258; C3: 861 with --batch 64)")
+    ap.add_argument("--phonemes", type=int, default=50, help="phonemes per utterance (C2: 50; C3: 160)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency section (profiling runs)")
     ap.add_argument("--serial-generator", action="store_true",
@@ -124,7 +126,7 @@ def main():
     from vits_amd import synthetic
     net = build_model(device)
     # every rank synthesises its own utterances: same shapes, different ids / durations / speakers / noise
-    batch = synthetic.make_batch(1 + rank, [50] * args.batch, [258] * args.batch)
+    batch = synthetic.make_batch(1 + rank, [args.phonemes] * args.batch, [args.frames] * args.batch)
     d = to_device(batch, device)
     audio_s = batch.audio_seconds
 
@@ -183,7 +185,7 @@ def main():
                 lat.append(time.perf_counter() - t1)
             lat.sort()
         rtf = lat[len(lat) // 2] / synthetic.config_c1().audio_seconds
-        flops_step = algorithmic_flops([50] * args.batch, [258] * args.batch)
+        flops_step = algorithmic_flops([args.phonemes] * args.batch, [args.frames] * args.batch)
         result = {
             "metric": "audio-sec/sec at 44.1 kHz",
             "value": round(world * args.steps * audio_s / elapsed, 2),
@@ -198,9 +200,11 @@ def main():
             "dtype": "f32",
             "conv_precision": net.precision,
             "data": "synthetic",
-            "config": {"workload": f"C2: batch {args.batch} x 50 phonemes x 258 frames (3.0 s each), fixed durations, "
-                                   "fixed noise, fp32; one batch per GPU per step",
-                       "batch_per_gpu": args.batch, "frames": 258, "parallelism": f"utterance-dp{world}"},
+            "config": {"workload": f"{'C2' if (args.batch, args.frames) == (16, 258) else 'custom'}: batch {args.batch} x "
+                                   f"{args.phonemes} phonemes x {args.frames} frames "
+                                   f"({args.frames * 512 / 44100:.1f} s each), fixed durations, fixed noise, fp32; "
+                                   "one batch per GPU per step",
+                       "batch_per_gpu": args.batch, "frames": args.frames, "parallelism": f"utterance-dp{world}"},
             "whole_path_tflops": round(world * args.steps * flops_step / elapsed / 1e12, 2),
             "rtf_batch1": None if args.no_latency else round(rtf, 5),
             "batch1_latency_ms": None if args.no_latency else round(lat[len(lat) // 2] * 1e3, 3),

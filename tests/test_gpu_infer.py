@@ -100,3 +100,36 @@ def test_infer_errors(gpu_model):
                                                                     duration_control=b.durations)
     assert o.shape == (1, 1, 20 * 512) and torch.isfinite(o).all()
     assert m_p.shape == logs_p.shape == z.shape == (1, 192, 20)
+
+
+def test_infer_c3_fullsize_properties(gpu_model):
+    """BASELINE configs[2] shape (64 utterances x 861 frames, 160 phonemes): too large for the CPU oracle in a test,
+    so it is checked through properties that do not depend on size: equal lengths => a row equals its own batch-1
+    result; same inputs => same bytes; output finite and inside tanh's range."""
+    b = synthetic.config_c3()
+    kw = dict(noise_scale=b.noise_scale, duration_control=b.durations)
+    o = gpu_model.infer(b.phonemes, b.lengths, sid=b.sid, noise=b.noise, **kw)[0]
+    assert o.shape == (64, 1, 861 * 512)
+    assert torch.isfinite(o).all() and float(o.abs().max()) <= 1.0
+    for i in (0, 37, 63):
+        o1 = gpu_model.infer(b.phonemes[i:i + 1], b.lengths[i:i + 1], sid=b.sid[i:i + 1], noise=b.noise[i:i + 1],
+                             noise_scale=b.noise_scale, duration_control=b.durations[i:i + 1])[0]
+        assert metrics.max_abs(o1[0], o[i]) <= 1e-5
+    o2 = gpu_model.infer(b.phonemes, b.lengths, sid=b.sid, noise=b.noise, **kw)[0]
+    assert torch.equal(o, o2)
+
+
+def test_infer_exact_fp32_mode(synthetic_sd):
+    """precision="fp32" (v_mfma_f32_32x32x2_f32 kernels) end to end against the reference goldens."""
+    from vits_amd import SynthesizerTrn
+    cfg = synthetic.ModelConfig()
+    net = SynthesizerTrn(cfg.n_vocab, cfg.spec_channels, cfg.hop_length, cfg.sampling_rate, cfg.segment_size,
+                         precision="fp32", **cfg.kwargs()).eval()
+    net.load_state_dict(synthetic_sd)
+    for name in ("ragged_b2", "tensor_controls"):
+        d, meta = load_case(name)
+        o, _, (z, z_p, m_p, logs_p), *_ = net.infer(d["in_phonemes"], d["in_lengths"], sid=d["in_sid"],
+                                                    noise=d["out_noise"], **infer_kwargs(d, meta))
+        assert metrics.max_abs(z, d["out_z"]) <= LATENT_TOL
+        assert metrics.max_abs(o, d["out_o"]) <= WAV_TOL
+        assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= MEL_TOL
