@@ -49,17 +49,22 @@ def gpu_conv(N, w, bias, x, dilation=1, mode=0, flags=0, lengths=None, cbias=Non
 
 
 CONV_CASES = [
-    # cout, cin, k, dil, B, L
-    (64, 32, 3, 1, 2, 300),       # <2,2,1,4>
+    # cout, cin, k, dil, B, L        (short launches run on the split-K kernel in bf16x3 mode, long ones on the one-role
+    #                                 kernel; the comments name the one-role tile they select)
+    (64, 32, 3, 1, 2, 300),       # cin < 64: one-role <2,2,1,4>
     (256, 256, 11, 5, 1, 700),    # widest receptive field (halo 50)
-    (32, 32, 7, 3, 2, 1500),      # <1,4,1,4>
+    (32, 32, 7, 3, 2, 1500),      # 32 rows: <1,2,1,4> (fp32 mode: <1,4,1,4>)
     (32, 64, 3, 1, 1, 250),       # <1,2,1,4>
     (96, 192, 1, 1, 2, 70),       # <1,1,1,4>
-    (768, 192, 3, 1, 2, 50),      # <2,1,2,2> short sequence
-    (192, 768, 3, 1, 3, 37),
+    (768, 192, 3, 1, 2, 50),      # short sequence
+    (192, 768, 3, 1, 3, 37),      # deep reduction, 48 channel chunks
     (576, 192, 1, 1, 2, 258),
     (512, 192, 7, 1, 1, 258),
     (64, 16, 5, 1, 1, 1),         # single time step
+    (64, 64, 7, 3, 4, 20000),     # long: one-role <2,2,1,4>
+    (128, 128, 3, 1, 4, 9000),    # long: one-role <2,2,2,2>
+    (256, 256, 3, 1, 4, 4500),    # long: one-role <2,2,4,1>
+    (256, 256, 7, 1, 4, 4500),    # long and deep: split-K with many blocks per CU
 ]
 
 
@@ -101,10 +106,10 @@ def test_conv_prologue_epilogue_flags(N, prec):
     assert (got2 - ref2).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize("L", [40, 258, 700])
-def test_conv_gate(N, prec, L):
+@pytest.mark.parametrize("L,B", [(40, 2), (258, 2), (700, 2), (9000, 4)])     # the last one: one-role gate kernel
+def test_conv_gate(N, prec, L, B):
     g = torch.Generator().manual_seed(L)
-    H, k, B = 192, 5, 2
+    H, k = 192, 5
     w = torch.randn(2 * H, H, k, generator=g) / math.sqrt(H * k)
     b = torch.randn(2 * H, generator=g)
     x = torch.randn(B, H, L, generator=g)
