@@ -31,11 +31,11 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 matrix peak
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
-def build_model(device):
+def build_model(device, precision=None):
     from vits_amd import SynthesizerTrn, synthetic
     cfg = synthetic.ModelConfig()
     net = SynthesizerTrn(cfg.n_vocab, cfg.spec_channels, cfg.hop_length, cfg.sampling_rate, cfg.segment_size,
-                         **cfg.kwargs()).eval()
+                         precision=precision, **cfg.kwargs()).eval()
     net.to(device)
     net.load_state_dict(synthetic.synthetic_state_dict(cfg, include_enc_q=False), strict=True)
     return net
@@ -90,6 +90,15 @@ def cpu_baseline(sample_utts=4, runs=2):
                        f"best of {runs} runs after warm-up; PyTorch CPU oracle (oracle/mvts_oracle.py)"), out, b
 
 
+def workload_name(args):
+    shape = (args.batch, args.phonemes, args.frames)
+    if shape == (16, 50, 258) and args.precision != "bf16":
+        return "C2"
+    if shape == (64, 160, 861):
+        return "C3" if args.precision == "bf16" else "C3 shape"
+    return "custom"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +107,10 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--frames", type=int, default=258, help="frames per utterance (C2: 258; C3: 861 with --batch 64)")
     ap.add_argument("--phonemes", type=int, default=50, help="phonemes per utterance (C2: 50; C3: 160)")
+    ap.add_argument("--precision", choices=("fp32", "bf16x3", "bf16"), default=None,
+                    help="conv arithmetic: bf16x3 (default) and fp32 are fp32-grade (the C2 parity workload); bf16 runs "
+                         "the generator's convs in plain bf16 (BASELINE configs[2]: --batch 64 --frames 861 "
+                         "--phonemes 160 --precision bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency section (profiling runs)")
     ap.add_argument("--serial-generator", action="store_true",
@@ -124,7 +137,7 @@ def main():
         os.environ["VITS_GEN_STREAMS"] = "1"
     from vits_amd import _native as N
     from vits_amd import synthetic
-    net = build_model(device)
+    net = build_model(device, args.precision)
     # every rank synthesises its own utterances: same shapes, different ids / durations / speakers / noise
     batch = synthetic.make_batch(1 + rank, [args.phonemes] * args.batch, [args.frames] * args.batch)
     d = to_device(batch, device)
@@ -160,7 +173,8 @@ def main():
         dom = rows[0]
         conv_ms = sum(r["ms"] for r in rows)
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        peak = PEAK_FP32_MFMA_TFLOPS if dom["name"].startswith("conv_mfma_kernel") else PEAK_BF16X3_TFLOPS
+        peak = (PEAK_FP32_MFMA_TFLOPS if dom["name"].startswith("conv_mfma_kernel") else
+                PEAK_BF16_MFMA_TFLOPS if dom["name"].startswith("conv_bf16_kernel") else PEAK_BF16X3_TFLOPS)
         roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(achieved, 3), peak=round(peak, 1),
                         unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=pmc_traffic(dom["name"]),
                         launches_per_step=dom["count"] // args.steps,
@@ -197,12 +211,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if net.precision == "bf16" else "f32",
             "conv_precision": net.precision,
             "data": "synthetic",
-            "config": {"workload": f"{'C2' if (args.batch, args.frames) == (16, 258) else 'custom'}: batch {args.batch} x "
+            "config": {"workload": f"{workload_name(args)}: batch {args.batch} x "
                                    f"{args.phonemes} phonemes x {args.frames} frames "
-                                   f"({args.frames * 512 / 44100:.1f} s each), fixed durations, fixed noise, fp32; "
+                                   f"({args.frames * 512 / 44100:.1f} s each), fixed durations, fixed noise, "
+                                   f"{'bf16 generator convs' if net.precision == 'bf16' else 'fp32'}; "
                                    "one batch per GPU per step",
                        "batch_per_gpu": args.batch, "frames": args.frames, "parallelism": f"utterance-dp{world}"},
             "whole_path_tflops": round(world * args.steps * flops_step / elapsed / 1e12, 2),

@@ -50,7 +50,10 @@ class OracleSynthesizer:
     def __init__(self, state_dict: Dict[str, torch.Tensor], n_heads: int = 2, window: int = 4,
                  upsample_rates=(8, 8, 4, 2), upsample_kernel_sizes=(16, 16, 4, 4),
                  resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3, 5),) * 3,
-                 kernel_size: int = 3, n_speakers: int = 200):
+                 kernel_size: int = 3, n_speakers: int = 200, generator_bf16: bool = False):
+        # generator_bf16: emulate the build's "bf16" conv mode -- both operands of every MFMA conv of the generator
+        # (conv_pre, ups, ResBlock convs; not conv_post) rounded to nearest-even bf16, products accumulated in fp32
+        self.generator_bf16 = generator_bf16
         sd = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}
         w: Dict[str, torch.Tensor] = {}
         for k, v in sd.items():
@@ -205,24 +208,31 @@ class OracleSynthesizer:
     def generator(self, x, g):
         """reference models.py:284-303 and modules.py:206-219 (ResBlock1)."""
         w = self.w
-        x = F.conv1d(x, w["dec.conv_pre.weight"], w["dec.conv_pre.bias"], padding=3)
+        if self.generator_bf16:
+            def q(t):
+                return t.to(torch.bfloat16).to(torch.float32)
+        else:
+            def q(t):
+                return t
+        x = F.conv1d(q(x), q(w["dec.conv_pre.weight"]), w["dec.conv_pre.bias"], padding=3)
         x = x + F.conv1d(g, w["dec.cond.weight"], w["dec.cond.bias"])
         nk = len(self.rb_k)
         for i, (u, ku) in enumerate(self.ups):
             x = F.leaky_relu(x, LRELU_SLOPE)
-            x = F.conv_transpose1d(x, w[f"dec.ups.{i}.weight"], w[f"dec.ups.{i}.bias"], stride=u, padding=(ku - u) // 2)
+            x = F.conv_transpose1d(q(x), q(w[f"dec.ups.{i}.weight"]), w[f"dec.ups.{i}.bias"], stride=u,
+                                   padding=(ku - u) // 2)
             xs = None
             for j in range(nk):
                 r = i * nk + j
                 k = self.rb_k[j]
                 y = x
-                for q, d in enumerate(self.rb_d[j]):
+                for n, d in enumerate(self.rb_d[j]):
                     t = F.leaky_relu(y, LRELU_SLOPE)
-                    t = F.conv1d(t, w[f"dec.resblocks.{r}.convs1.{q}.weight"], w[f"dec.resblocks.{r}.convs1.{q}.bias"],
-                                 padding=(k * d - d) // 2, dilation=d)
+                    t = F.conv1d(q(t), q(w[f"dec.resblocks.{r}.convs1.{n}.weight"]),
+                                 w[f"dec.resblocks.{r}.convs1.{n}.bias"], padding=(k * d - d) // 2, dilation=d)
                     t = F.leaky_relu(t, LRELU_SLOPE)
-                    t = F.conv1d(t, w[f"dec.resblocks.{r}.convs2.{q}.weight"], w[f"dec.resblocks.{r}.convs2.{q}.bias"],
-                                 padding=(k - 1) // 2)
+                    t = F.conv1d(q(t), q(w[f"dec.resblocks.{r}.convs2.{n}.weight"]),
+                                 w[f"dec.resblocks.{r}.convs2.{n}.bias"], padding=(k - 1) // 2)
                     y = t + y
                 xs = y if xs is None else xs + y
             x = xs / nk

@@ -133,3 +133,41 @@ def test_infer_exact_fp32_mode(synthetic_sd):
         assert metrics.max_abs(z, d["out_z"]) <= LATENT_TOL
         assert metrics.max_abs(o, d["out_o"]) <= WAV_TOL
         assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= MEL_TOL
+
+
+BF16_WAV_TOL = 3e-2      # plain-bf16 generator against fp32: measured 8e-3 max-abs (rms 1.5e-3, 42 dB below the signal)
+BF16_MEL_TOL = 1e-2      # measured 2.7e-3
+
+
+def test_infer_bf16_generator_mode(synthetic_sd):
+    """precision="bf16": the generator's convs round both operands to bf16 (one MFMA product, fp32 accumulate);
+    everything upstream of z stays fp32-grade, so latents, masks and durations must still meet the fp32 tolerances.
+
+    The waveform is checked against the reference goldens (fp32) at the bf16 tolerances above, and against the oracle
+    emulating the same rounding.  That emulation is not a tighter check end to end: a value that sits next to a bf16
+    rounding boundary flips with any 1e-6 relative difference upstream (accumulation order), and 24 convs in series
+    amplify the flips -- perturbing the oracle's own z by 1e-6 relative moves its bf16 waveform by 5e-3 max-abs /
+    5e-4 rms.  The kernel's arithmetic itself is pinned per operator (tests/test_gpu_ops.py, bf16 cases: 2e-5 against
+    fp32 math on rounded operands)."""
+    from oracle.mvts_oracle import OracleSynthesizer
+    from vits_amd import SynthesizerTrn
+    cfg = synthetic.ModelConfig()
+    net = SynthesizerTrn(cfg.n_vocab, cfg.spec_channels, cfg.hop_length, cfg.sampling_rate, cfg.segment_size,
+                         precision="bf16", **cfg.kwargs()).eval()
+    net.load_state_dict(synthetic_sd)
+    emu = OracleSynthesizer(synthetic_sd, generator_bf16=True)
+    for name in ("ragged_b2", "predicted_scalar"):
+        d, meta = load_case(name)
+        kw = infer_kwargs(d, meta)
+        o, x_mask, (z, z_p, m_p, logs_p), duration, *_ = net.infer(d["in_phonemes"], d["in_lengths"], sid=d["in_sid"],
+                                                                   noise=d["out_noise"], **kw)
+        assert torch.equal(x_mask.cpu(), d["out_x_mask"])
+        assert torch.equal(duration.cpu().to(torch.float64), d["out_duration"].to(torch.float64))
+        assert metrics.max_abs(z, d["out_z"]) <= LATENT_TOL
+        assert o.shape == d["out_o"].shape
+        assert metrics.max_abs(o, d["out_o"]) <= BF16_WAV_TOL
+        assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= BF16_MEL_TOL
+        ref = emu.infer(d["in_phonemes"], d["in_lengths"], sid=d["in_sid"], noise=d["out_noise"], **kw)[0]
+        assert metrics.max_abs(o, ref) <= BF16_WAV_TOL
+        assert float((o.cpu() - ref).pow(2).mean().sqrt()) <= 3e-3          # measured 1e-3
+        assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= BF16_MEL_TOL

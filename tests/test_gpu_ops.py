@@ -22,12 +22,19 @@ def dev(t):
     return None if t is None else t.cuda().contiguous()
 
 
-PREC = {"fp32": 0, "bf16x3": 1}
+PREC = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 
 
-@pytest.fixture(params=["fp32", "bf16x3"])
+@pytest.fixture(params=["fp32", "bf16x3", "bf16"])
 def prec(request):
     return PREC[request.param]
+
+
+def rq(t, prec):
+    """A conv operand as the kernel multiplies it: the plain bf16 mode rounds weights and (after the input prologue)
+    activations to nearest-even bf16; products of two bf16 values are exact in fp32, so the CPU reference on rounded
+    operands differs from the kernel by accumulation order only and the fp32-grade tolerance applies unchanged."""
+    return t.to(torch.bfloat16).to(torch.float32) if prec == PREC["bf16"] else t
 
 
 def gpu_conv(N, w, bias, x, dilation=1, mode=0, flags=0, lengths=None, cbias=None, in_cbias=None, res=None,
@@ -74,7 +81,7 @@ def test_conv_plain(N, prec, cout, cin, k, dil, B, L):
     w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
     b = torch.randn(cout, generator=g)
     x = torch.randn(B, cin, L, generator=g)
-    ref = F.conv1d(x, w, b, padding=(k - 1) // 2 * dil, dilation=dil)
+    ref = F.conv1d(rq(x, prec), rq(w, prec), b, padding=(k - 1) // 2 * dil, dilation=dil)
     got = gpu_conv(N, w, b, x, dilation=dil, prec=prec)
     assert got.shape == ref.shape
     assert (got - ref).abs().max() < 2e-5
@@ -94,14 +101,14 @@ def test_conv_prologue_epilogue_flags(N, prec):
     init = torch.randn(B, cout, L, generator=g)
     # input: ((x + in_cbias) * scale) -> lrelu -> mask ; output: relu -> mask -> + res -> + out -> mask
     xin = F.leaky_relu((x + icb[:, :, None]) * 0.5, 0.1) * m
-    y = F.conv1d(xin, w, b, padding=1) + cbias[:, :, None]
+    y = F.conv1d(rq(xin, prec), rq(w, prec), b, padding=1) + cbias[:, :, None]
     ref = ((torch.relu(y) * m) + res + init) * m
     flags = N.F_IN_LRELU | N.F_IN_MASK | N.F_RELU | N.F_MASK_PRE | N.F_RES | N.F_ACCUM | N.F_MASK_POST
     got = gpu_conv(N, w, b, x, flags=flags, lengths=lengths, cbias=cbias, in_cbias=icb, res=res, out_init=init,
                    in_scale=0.5, in_slope=0.1, prec=prec)
     assert (got - ref).abs().max() < 2e-5
     # res - y form used by the coupling layer
-    ref2 = (res - (F.conv1d(x, w, b, padding=1) * m)) * m
+    ref2 = (res - (F.conv1d(rq(x, prec), rq(w, prec), b, padding=1) * m)) * m
     got2 = gpu_conv(N, w, b, x, flags=N.F_MASK_PRE | N.F_RES_SUB | N.F_MASK_POST, lengths=lengths, res=res, prec=prec)
     assert (got2 - ref2).abs().max() < 2e-5
 
@@ -114,7 +121,7 @@ def test_conv_gate(N, prec, L, B):
     b = torch.randn(2 * H, generator=g)
     x = torch.randn(B, H, L, generator=g)
     cb = torch.randn(B, 2 * H, generator=g)
-    a = F.conv1d(x, w, b, padding=2) + cb[:, :, None]
+    a = F.conv1d(rq(x, prec), rq(w, prec), b, padding=2) + cb[:, :, None]
     ref = torch.tanh(a[:, :H]) * torch.sigmoid(a[:, H:])
     got = gpu_conv(N, w, b, x, mode=N.MODE_GATE, cbias=cb, prec=prec)
     assert (got - ref).abs().max() < 2e-5
@@ -130,7 +137,8 @@ def test_conv_transpose(N, prec, u, k, cin, cout, L):
     x = torch.randn(2, cin, L, generator=g)
     if cout * u % 64:
         pytest.skip("rows must be a multiple of 64")
-    ref = F.conv_transpose1d(F.leaky_relu(x / 3, 0.1), wt, b, stride=u, padding=(k - u) // 2)
+    # x * float32(1/3) as the kernel's in_scale does (x / 3 differs in the last bit, which can flip a bf16 rounding)
+    ref = F.conv_transpose1d(rq(F.leaky_relu(x * (1.0 / 3), 0.1), prec), rq(wt, prec), b, stride=u, padding=(k - u) // 2)
     w_rows, b_rows, mode, taps = weights.transposed_conv_rows(wt, b, u, k, (k - u) // 2)
     got = gpu_conv(N, w_rows, None, x, mode=mode, up=u, bias_rows=b_rows, flags=N.F_IN_LRELU, in_scale=1.0 / 3,
                    in_slope=0.1, prec=prec)

@@ -48,6 +48,37 @@ def test_pack_roundtrip():
     assert np.array_equal(unpack(weights.pack_rows(w), 64, 32, 5), w.numpy())
 
 
+def test_pack_bf16_planes():
+    """bf16 fragment order [cin/16][taps][rows/32][plane][64 lanes][8]: lane l of m-tile mt holds
+    W[mt*32 + (l & 31)][16*chunk + 8*(l >> 5) + j][tap]; the plain mode stores the round-to-nearest-even bf16 value,
+    the bf16x3 mode three planes that sum back to the fp32 value exactly."""
+    torch.manual_seed(2)
+    rows, cin, taps = 64, 32, 3
+    w = torch.randn(rows, cin, taps)
+    w[0, 0, 0] = 1.0 + 2.0 ** -8             # exactly half way between two bf16 values: ties go to even (1.0)
+    w[1, 0, 0] = 1.0 + 3 * 2.0 ** -8         # tie, rounds up to even (1 + 2^-6)
+
+    def values(packed, planes):
+        bits = packed.view(torch.int16).to(torch.int32) & 0xffff
+        f = (bits << 16).view(torch.float32) if bits.dtype == torch.int32 else None
+        f = f.reshape(cin // 16, taps, rows // 32, planes, 64, 8).double()
+        out = torch.zeros(planes, rows, cin, taps, dtype=torch.float64)
+        for lane in range(64):
+            for j in range(8):
+                ci = torch.arange(cin // 16) * 16 + 8 * (lane >> 5) + j
+                # f[:, :, :, p, lane, j] is [chunk, tap, mt]
+                for p_ in range(planes):
+                    out[p_, (lane & 31)::32][:, ci, :] = f[:, :, :, p_, lane, j].permute(2, 0, 1)
+        return out
+
+    one = values(weights.pack_rows(w, N.PREC_BF16), 1)[0]
+    assert torch.equal(one.float(), w.to(torch.bfloat16).float())
+    assert one[0, 0, 0] == 1.0 and one[1, 0, 0] == 1.0 + 2.0 ** -6
+    three = values(weights.pack_rows(w, N.PREC_BF16X3), 3)
+    assert torch.equal(three.sum(0).float(), w)
+    assert torch.equal(three[0].float(), one.float())
+
+
 def emulate_transposed(w_rows, bias_rows, mode, x, up):
     """What the conv kernel computes for a transposed conv: GEMM rows with per-class tap offsets, then the
     row -> (channel, phase) scatter of its epilogue."""
@@ -88,7 +119,11 @@ def test_prepare_covers_every_used_key(synthetic_sd):
     pw = weights.prepare(synthetic_sd, cfg)
     assert len(pw.convs) == 14 * 4 + 2 + 2 + 1 + 4 * (2 + 4 + 3 + 4) + 1 + 4 + 72
     flow0 = pw.convs["flow.0.in.0"]
-    assert flow0[2:] == (192, 384, 5, 1, N.MODE_GATE)
+    assert flow0[2:] == (192, 384, 5, 1, N.MODE_GATE, N.PREC_F32)
+    # model-level "bf16": only the generator's convs are plain bf16, everything upstream of z stays fp32-grade
+    pb = weights.prepare(synthetic_sd, cfg, N.PREC_BF16)
+    assert {v[7] for k, v in pb.convs.items() if k.startswith("dec.")} == {N.PREC_BF16}
+    assert {v[7] for k, v in pb.convs.items() if not k.startswith("dec.")} == {N.PREC_BF16X3}
     assert pw.plain["cond.w"].numel() == (3 * 192 + 512 + 4 * 1536) * 256
 
 

@@ -50,6 +50,7 @@ def _load():
         "vits_model_finalize": (i32, [vp]),
         "vits_pack_conv_weight": (i32, [vp, i32, i32, i32, vp]),
         "vits_pack_conv_weight_bf16x3": (i32, [vp, i32, i32, i32, vp]),
+        "vits_pack_conv_weight_bf16": (i32, [vp, i32, i32, i32, vp]),
         "vits_cond_rows": (i32, [vp]),
         "vits_speaker_cond": (i32, [vp, vp, i32, vp, vp, vp]),
         "vits_encoder_workspace_bytes": (i64, [vp, i32, i32]),
@@ -83,8 +84,8 @@ def _load():
 lib, EXPORTED = _load()
 
 MODE_PLAIN, MODE_GATE, MODE_UP8, MODE_UP4, MODE_UP2 = 0, 1, 2, 3, 4
-PREC_F32, PREC_BF16X3 = 0, 1
-PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3}
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 F_IN_LRELU, F_IN_MASK, F_RELU, F_MASK_PRE, F_RES, F_RES_SUB, F_ACCUM, F_MASK_POST = (1 << i for i in range(8))
 
 

@@ -13,11 +13,12 @@
 //   The next channel chunk is prefetched into registers while the current chunk is multiplied.
 //   C/D: column = time = lane & 31, so every accumulator register stores 128 contiguous bytes per half wave.
 //
-// Two arithmetic modes share tiling, prologue and epilogue:
+// Three arithmetic modes share tiling, prologue and epilogue:
 //   PREC_F32     v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (64 FLOP/clk/SIMD).
 //   PREC_BF16X3  every fp32 operand is split exactly into three bf16 terms (x = h + m + l, 24 significant bits) and
 //                the six largest cross products (hh, hm, mh, hl, lh, mm) run on v_mfma_f32_32x32x16_bf16 with fp32
 //                accumulation: fp32-grade results (dropped terms < 2^-24 relative) at 16/6 of the fp32 MFMA rate.
+//   PREC_BF16    both operands rounded to bf16, one product, fp32 accumulation (8 significant bits per operand).
 #include "common.h"
 
 #include <cstdio>
@@ -658,6 +659,156 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, uns
 template <int V>
 struct IntC { static constexpr int value = V; };
 
+
+// ---------------------------------------------------------------------------------------------------------
+// PREC_BF16 kernel: one bf16 product per multiply-accumulate.  Both operands are rounded to nearest-even bf16 (the
+// weights on the host at packing time, the activations at staging after the input prologue) and accumulated in fp32
+// on v_mfma_f32_32x32x16_bf16.  Same tiling, staging order and epilogue as the bf16x3 kernel with one plane instead
+// of three: weights [Cin/16][tap][M/32][64 lanes][8 bf16], LDS [2 halves][ncols] of 8 bf16.  A sixth of the
+// matrix work for the same activation traffic, so the long layers of the generator run at the rate HBM delivers
+// their fp32 inputs, residuals and outputs.
+// ---------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int WGM, int WGN, int MODE>
+__global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(const ConvArgs a) {
+  constexpr int BN = 32 * WN * WGN;
+  constexpr int NCT = (BN + MAX_HALO + 255) / 256;       // tile columns per thread
+  constexpr bool TWO_CLASS = (MODE == MODE_UP8 || MODE == MODE_UP2);
+  constexpr int NB = TWO_CLASS ? 2 : 1;
+  static_assert(WGM * WGN == 4, "four waves per block");
+  static_assert(!TWO_CLASS || WM == 2, "two-class transposed convs pair the classes in one wave");
+  static_assert(MODE != MODE_GATE || WM == 2, "gate pairs the tanh and sigmoid rows in one wave");
+
+  extern __shared__ __attribute__((aligned(16))) uint4 xq[];    // [2 halves][ncols] of 8 bf16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int par = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BN;
+  const int len_b = a.lengths ? a.lengths[b] : 0x7fffffff;
+  const int ncols = a.rs;
+
+  int mt[WM];
+  bool mt_ok[WM];
+  wave_mtiles<WM, WGM, MODE>(a, wm, mt, mt_ok);
+
+  const float* xb = a.x + (long long)b * a.x_bs;
+  const int tstart = t0 + a.min_off;
+  const int wcols = a.width;
+  float st[NCT][16];
+  auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NCT; ++q) {
+      const int col = tid + 256 * q, t = tstart + col;
+      const bool ok = col < wcols && t >= 0 && t < a.L;
+      const float* xc = xb + (long long)chunk * 16 * a.x_cs + (ok ? t : 0);
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci) {
+        const float v = xc[(long long)ci * a.x_cs];
+        st[q][ci] = ok ? v : 0.f;
+      }
+    }
+  };
+  auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
+    const float* cbp = a.in_cbias ? a.in_cbias + (long long)b * a.in_cbias_bs + chunk * 16 : nullptr;
+#pragma unroll
+    for (int q = 0; q < NCT; ++q) {
+      const int col = tid + 256 * q, t = tstart + col;
+      if (col < wcols) {
+        bool ok = t >= 0 && t < a.L;
+        if (a.flags & F_IN_MASK) ok = ok && t < len_b;
+        unsigned ph[8];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+          f32x2 v;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int ci = 2 * c2 + u;
+            float e = (st[q][ci] + (cbp ? cbp[ci] : 0.f)) * a.in_scale;
+            if (a.flags & F_IN_LRELU) e = fmaxf(e, e * a.in_slope);
+            v[u] = ok ? e : 0.f;
+          }
+          ph[c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        }
+        xq[col] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        xq[ncols + col] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // weight fragments: index ((chunk*K + tap) * mt_total + mt) * 64 + lane, in 16-byte units
+  const uint4* w16 = reinterpret_cast<const uint4*>(a.w);
+  const uint4* wp[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) wp[i] = w16 + (long long)mt[i] * 64 + lane;
+  const long long it_stride = (long long)a.mt_total * 64;
+  const int nchunks = a.Cin / 16;
+  const int n_it = nchunks * a.K;
+  uint4 A[WM], An[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) A[i] = wp[i][0];
+  int it = 0;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  const int colbase = wn * WN * 32 + l31 + par * ncols - a.min_off;
+  uint4 B[NB][WN], Bn[NB][WN];
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+    int boff[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      boff[c] = colbase + a.toff0[c];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) B[c][j] = xq[boff[c] + j * 32];
+    }
+    for (int k = 0; k < a.K; ++k) {
+      // operands of the next tap are requested before this tap's products (a chunk's last tap re-reads its own
+      // activation fragments, the last tap of all its own weights: straight-line code, exact waits)
+      ++it;
+      const long long nxt = (long long)(it < n_it ? it : n_it - 1) * it_stride;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) An[i] = wp[i][nxt];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        if (k + 1 < a.K) boff[c] += a.tstep[c];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) Bn[c][j] = xq[boff[c] + j * 32];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[i]),
+                                                              __builtin_bit_cast(bf16x8, B[TWO_CLASS ? i : 0][j]),
+                                                              acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < WM; ++i) A[i] = An[i];
+#pragma unroll
+      for (int c = 0; c < NB; ++c)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) B[c][j] = Bn[c][j];
+    }
+    if (chunk + 1 < nchunks) {
+      __syncthreads();
+      store_chunk(chunk + 1);
+      __syncthreads();
+    }
+  }
+
+  conv_epilogue<WM, WN, MODE, true>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
@@ -714,6 +865,21 @@ static hipError_t launch_b3(ConvArgs& a, hipStream_t stream) {
   snprintf(name, sizeof name, "conv_bf16x3_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
   return timed_launch(name, a, stream, [&] {
     hipLaunchKernelGGL((conv_bf16x3_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
+  });
+}
+
+template <int WM, int WN, int WGM, int WGN, int MODE>
+static hipError_t launch_b1(ConvArgs& a, hipStream_t stream) {
+  constexpr int BN = 32 * WN * WGN;
+  a.width = BN + (a.width);
+  a.rs = a.width;                    // columns per half slab
+  const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + WM - 1) / WM;
+  dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
+  const size_t lds = (size_t)2 * a.rs * sizeof(uint4);
+  char name[96];
+  snprintf(name, sizeof name, "conv_bf16_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
+  return timed_launch(name, a, stream, [&] {
+    hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
   });
 }
 
@@ -999,6 +1165,7 @@ static bool try_launch_ks(ConvArgs& a, hipStream_t stream, hipError_t& err) {
 template <int WM, int WN, int WGM, int WGN, int MODE>
 static hipError_t launch_cfg(ConvArgs& a, int prec, hipStream_t stream) {
   if (prec == PREC_BF16X3) return launch_b3<WM, WN, WGM, WGN, MODE>(a, stream);
+  if (prec == PREC_BF16) return launch_b1<WM, WN, WGM, WGN, MODE>(a, stream);
   // dwordx4 staging needs 16-byte aligned rows and whole groups of four time steps
   const bool vec = a.L % 4 == 0 && a.x_cs % 4 == 0 && a.x_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
   if (vec) return launch_f32<WM, WN, WGM, WGN, MODE, true>(a, stream);

@@ -33,7 +33,8 @@ class SynthesizerTrn:
             raise NotImplementedError("only resblock='1' (ResBlock1) is implemented; the reference config uses it")
         if n_speakers <= 1 or gin_channels <= 0:
             raise NotImplementedError("a speaker-conditioned model (n_speakers > 1, gin_channels > 0) is required")
-        # arithmetic of the conv kernels: "bf16x3" (default) or "fp32"; keyword `precision` or env VITS_PRECISION
+        # arithmetic of the conv kernels: "bf16x3" (default) and "fp32" give fp32-grade results; "bf16" runs the
+        # generator's convs in plain bf16 (fp32 accumulate).  Keyword `precision` or env VITS_PRECISION
         prec = kwargs.pop("precision", None) or os.environ.get("VITS_PRECISION", "bf16x3")
         if prec not in N.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(N.PRECISIONS)}")
@@ -84,7 +85,7 @@ class SynthesizerTrn:
 
     def __del__(self):
         h = getattr(self, "_handle", None)
-        if h is not None and h.value:
+        if h is not None and h.value and N is not None and getattr(N, "lib", None) is not None:   # not at interpreter exit
             N.lib.vits_model_destroy(h)
             self._handle = C.c_void_p()
 
@@ -148,12 +149,12 @@ class SynthesizerTrn:
                 d = t.to(self.device)
                 self._device_tensors.append(d)
                 N.check(N.lib.vits_model_set_tensor(h, name.encode(), d.data_ptr(), d.numel()), f"set_tensor {name}")
-            for name, (w, b, cin, rows, taps, dil, mode) in pw.convs.items():
+            for name, (w, b, cin, rows, taps, dil, mode, prec) in pw.convs.items():
                 dw = w.to(self.device)
                 db = None if b is None else b.to(self.device)
                 self._device_tensors += [dw, db]
                 N.check(N.lib.vits_model_set_conv(h, name.encode(), dw.data_ptr(), N.ptr(db), cin, rows, taps, dil, mode,
-                                                  pw.precision),
+                                                  prec),
                         f"set_conv {name}")
             N.check(N.lib.vits_model_finalize(h), "vits_model_finalize")
             torch.cuda.synchronize(self.device)

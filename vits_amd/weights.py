@@ -32,13 +32,17 @@ def folded(sd: Dict[str, torch.Tensor], base: str) -> torch.Tensor:
 
 
 def pack_rows(w_rows: torch.Tensor, precision: int = N.PREC_F32) -> torch.Tensor:
-    """[rows, cin, taps] fp32 (CPU) -> flat packed fragment order used by the conv kernel (fp32, or three bf16
-    planes stored as int16 bit patterns for the bf16x3 mode)."""
+    """[rows, cin, taps] fp32 (CPU) -> flat packed fragment order used by the conv kernel (fp32; three bf16
+    planes stored as int16 bit patterns for the bf16x3 mode; one plane for the plain bf16 mode)."""
     w_rows = w_rows.contiguous().float()
     rows, cin, taps = w_rows.shape
     if precision == N.PREC_BF16X3:
         out = torch.empty(3 * rows * cin * taps, dtype=torch.int16)
         N.check(N.lib.vits_pack_conv_weight_bf16x3(w_rows.data_ptr(), rows, cin, taps, out.data_ptr()), "pack_bf16x3")
+        return out
+    if precision == N.PREC_BF16:
+        out = torch.empty(rows * cin * taps, dtype=torch.int16)
+        N.check(N.lib.vits_pack_conv_weight_bf16(w_rows.data_ptr(), rows, cin, taps, out.data_ptr()), "pack_bf16")
         return out
     out = torch.empty(rows * cin * taps, dtype=torch.float32)
     N.check(N.lib.vits_pack_conv_weight(w_rows.data_ptr(), rows, cin, taps, out.data_ptr()), "pack_conv_weight")
@@ -98,9 +102,16 @@ class PreparedWeights:
     """CPU-side result of preparing a checkpoint: plain tensors and packed convs keyed by library names."""
 
     def __init__(self, precision: int = N.PREC_F32):
+        # model-level mode.  PREC_BF16 means: the generator's convs ("dec.*", 97 % of the FLOPs) in plain bf16, every
+        # conv upstream of the latent z in bf16x3, so durations, masks and latents are those of the fp32-grade modes
         self.precision = precision
         self.plain: Dict[str, torch.Tensor] = {}
-        self.convs: Dict[str, Tuple[torch.Tensor, torch.Tensor, int, int, int, int, int]] = {}
+        self.convs: Dict[str, Tuple[torch.Tensor, torch.Tensor, int, int, int, int, int, int]] = {}
+
+    def conv_precision(self, name: str) -> int:
+        if self.precision == N.PREC_BF16 and not name.startswith("dec."):
+            return N.PREC_BF16X3
+        return self.precision
 
     def add_plain(self, name: str, t: torch.Tensor):
         self.plain[name] = t.detach().float().contiguous().reshape(-1)
@@ -108,7 +119,8 @@ class PreparedWeights:
     def add_conv(self, name: str, w_rows: torch.Tensor, bias_rows, dilation: int = 1, mode: int = N.MODE_PLAIN):
         rows, cin, taps = w_rows.shape
         b = None if bias_rows is None else bias_rows.detach().float().contiguous()
-        self.convs[name] = (pack_rows(w_rows, self.precision), b, cin, rows, taps, dilation, mode)
+        prec = self.conv_precision(name)
+        self.convs[name] = (pack_rows(w_rows, prec), b, cin, rows, taps, dilation, mode, prec)
 
 
 ENCODERS = (("enc_p.encoder", "n_layers"), ("pitch_predictor.pitch_net", "pitch_layers"),
