@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (256 CUs x 256 FLOP/clk x 2.4 GHz)
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 matrix peak
+PEAK_HBM_GBPS = 8000.0             # MI355X HBM3E
 # bf16x3 kernels spend six bf16 MFMA products per algorithmic fp32 product
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
@@ -90,6 +91,51 @@ def cpu_baseline(sample_utts=4, runs=2):
                        f"best of {runs} runs after warm-up; PyTorch CPU oracle (oracle/mvts_oracle.py)"), out, b
 
 
+def run_corpus(net, args, device, rank, world, dist):
+    """BASELINE configs[3]: a synthetic corpus (lognormal lengths, 88..1400 frames) sorted by length, cut into
+    batches of <= 64 utterances whose composition does not depend on the rank count, whole batches dealt to ranks
+    longest-first; every rank synthesises its own batches with no collective on the data path.  Inputs of all of a
+    rank's batches are resident in HBM before the clock starts.  value = corpus audio-seconds / slowest rank's time."""
+    from vits_amd import sharding, synthetic
+    batches = synthetic.corpus_c4(args.utterances, max_batch=args.batch if args.batch != 16 else 64)
+    mine = sharding.deal_batches(batches, world, rank)
+    data = []
+    for i in mine:
+        ps, ts = batches[i]
+        data.append(to_device(synthetic.make_batch(1000 + i, ps, ts), device))
+    # warm-up on the rank's largest batch first (sizes the workspace once), then on its smallest
+    order = sorted(range(len(mine)), key=lambda j: -sharding.batch_cost(batches[mine[j]]))
+    for j in ([order[0], order[-1]] if order else []):
+        step(net, data[j])
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for d in data:
+        step(net, d)
+    torch.cuda.synchronize(device)
+    mine_s = time.perf_counter() - t0
+    elapsed = mine_s
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)      # reporting only: the slowest rank's wall time
+        elapsed = float(t.item())
+    if rank == 0:
+        frames = sum(sum(ts) for _, ts in batches)
+        audio_s = frames * 512 / 44100.0
+        flops = sum(algorithmic_flops(ps, ts) for ps, ts in batches)
+        print(json.dumps({
+            "metric": "audio-sec/sec at 44.1 kHz", "value": round(audio_s / elapsed, 2), "unit": "audio-s/s",
+            "n_gpus": world, "steps": len(mine), "warmup": 2, "ms_per_step": round(mine_s / max(len(mine), 1) * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if net.precision == "bf16" else "f32", "conv_precision": net.precision, "data": "synthetic",
+            "config": {"workload": f"C4: corpus of {args.utterances} utterances ({audio_s:.0f} audio-s, {frames} frames, "
+                                   f"88..1400 frames each), {len(batches)} length-sorted batches of <= 64 dealt "
+                                   "longest-first to the ranks; a step is one batch",
+                       "utterances": args.utterances, "batches": len(batches), "parallelism": f"utterance-dp{world}"},
+            "whole_path_tflops": round(flops / elapsed / 1e12, 2), "seconds": round(elapsed, 3)}), flush=True)
+
+
 def workload_name(args):
     shape = (args.batch, args.phonemes, args.frames)
     if shape == (16, 50, 258) and args.precision != "bf16":
@@ -111,6 +157,10 @@ def main():
                     help="conv arithmetic: bf16x3 (default) and fp32 are fp32-grade (the C2 parity workload); bf16 runs "
                          "the generator's convs in plain bf16 (BASELINE configs[2]: --batch 64 --frames 861 "
                          "--phonemes 160 --precision bf16)")
+    ap.add_argument("--workload", choices=("batch", "c4"), default="batch",
+                    help="batch (default): one fixed batch per step (C2; C3 with --batch/--frames/--phonemes); "
+                         "c4: the sharded synthetic corpus of BASELINE configs[3]")
+    ap.add_argument("--utterances", type=int, default=10000, help="corpus size for --workload c4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency section (profiling runs)")
     ap.add_argument("--serial-generator", action="store_true",
@@ -138,6 +188,12 @@ def main():
     from vits_amd import _native as N
     from vits_amd import synthetic
     net = build_model(device, args.precision)
+    if args.workload == "c4":
+        run_corpus(net, args, device, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # every rank synthesises its own utterances: same shapes, different ids / durations / speakers / noise
     batch = synthetic.make_batch(1 + rank, [args.phonemes] * args.batch, [args.frames] * args.batch)
     d = to_device(batch, device)
@@ -175,13 +231,23 @@ def main():
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         peak = (PEAK_FP32_MFMA_TFLOPS if dom["name"].startswith("conv_mfma_kernel") else
                 PEAK_BF16_MFMA_TFLOPS if dom["name"].startswith("conv_bf16_kernel") else PEAK_BF16X3_TFLOPS)
-        roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(achieved, 3), peak=round(peak, 1),
-                        unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=pmc_traffic(dom["name"]),
+        gbps = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        # the bound is whichever roof the kernel's arithmetic intensity puts lower: the plain-bf16 generator layers
+        # (64 / 32 channels) sit under the HBM roof, the fp32-grade modes under the MFMA roof
+        if dom["flops"] / dom["bytes"] < peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
+            roof = dict(bound="hbm", kernel=dom["name"], achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                        frac=round(gbps / PEAK_HBM_GBPS, 4), tflops=round(achieved, 3))
+        else:
+            roof = dict(bound="mfma", kernel=dom["name"], achieved=round(achieved, 3), peak=round(peak, 1),
+                        unit="TFLOP/s", frac=round(achieved / peak, 4), algorithmic_gbps=round(gbps, 1))
+        roofline = dict(roof, traffic=pmc_traffic(dom["name"]),
+                        algorithmic_bytes_per_launch=round(dom["bytes"] / dom["count"]),
                         launches_per_step=dom["count"] // args.steps,
                         avg_launch_us=round(dom["ms"] * 1e3 / dom["count"], 2),
                         flops_per_launch=round(dom["flops"] / dom["count"]),
                         share_of_conv_time=round(dom["ms"] / conv_ms, 3),
                         all_conv_kernels=[dict(kernel=r["name"], tflops=round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                                               gbps=round(r["bytes"] / (r["ms"] * 1e-3) / 1e9),
                                                ms_per_step=round(r["ms"] / args.steps, 3),
                                                launches_per_step=r["count"] // args.steps) for r in rows])
         # batch-1 latency (3.0 s utterance)
@@ -198,6 +264,19 @@ def main():
                 torch.cuda.synchronize(device)
                 lat.append(time.perf_counter() - t1)
             lat.sort()
+            # configs[4]: the same utterance with per-phoneme F0 / energy / duration overrides (tensor controls)
+            c5 = synthetic.config_c5()
+            d5 = to_device(c5, device)
+            kw5 = dict(sid=d5["sid"], noise_scale=0.667, duration_control=d5["durations"], noise=d5["noise"],
+                       pitch_control=c5.pitch_hz.to(device), energy_control=c5.energy.to(device))
+            lat5 = []
+            for i in range(23):
+                t1 = time.perf_counter()
+                net.infer(d5["phonemes"], d5["lengths"], **kw5)
+                torch.cuda.synchronize(device)
+                if i >= 3:
+                    lat5.append(time.perf_counter() - t1)
+            lat5.sort()
         rtf = lat[len(lat) // 2] / synthetic.config_c1().audio_seconds
         flops_step = algorithmic_flops([args.phonemes] * args.batch, [args.frames] * args.batch)
         result = {
@@ -223,6 +302,7 @@ def main():
             "whole_path_tflops": round(world * args.steps * flops_step / elapsed / 1e12, 2),
             "rtf_batch1": None if args.no_latency else round(rtf, 5),
             "batch1_latency_ms": None if args.no_latency else round(lat[len(lat) // 2] * 1e3, 3),
+            "batch1_edit_latency_ms": None if args.no_latency else round(lat5[len(lat5) // 2] * 1e3, 3),
             "roofline": roofline,
         }
         if not args.no_cpu_baseline:

@@ -130,6 +130,9 @@ int vits_generator(const vits_model* m, const float* z, const int* frame_lengths
 void vits_profile_enable(int on);
 void vits_profile_reset(void);
 int vits_profile_read(int index, char* name, int name_len, double* flops, double* ms, int64_t* count);
+/* Algorithmic HBM bytes summed over the launches of row `index` (same row order as vits_profile_read): every input
+ * and output element once in fp32, residual / accumulated-output reads where the epilogue has them, packed weights. */
+int vits_profile_read_bytes(int index, double* bytes);
 
 /* ---- single operators, exposed for unit parity tests ---- */
 int vits_op_conv1d(const void* packed_w, const float* bias_rows, int cin, int rows, int taps, int dilation, int mode,

@@ -68,6 +68,7 @@ def _load():
         "vits_generator": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp]),
         "vits_profile_enable": (None, [i32]),
         "vits_profile_reset": (None, []),
+        "vits_profile_read_bytes": (i32, [i32, C.POINTER(C.c_double)]),
         "vits_profile_read": (i32, [i32, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int64)]),
         "vits_op_conv1d": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, f32, f32, vp]),
@@ -100,12 +101,14 @@ def ptr(t) -> int:
 
 
 def profile_rows():
-    """Resolve and return the per-kernel timing rows: list of dict(name, flops, ms, count)."""
+    """Resolve and return the per-kernel timing rows: list of dict(name, flops, ms, count, bytes)."""
     n = lib.vits_profile_read(-1, None, 0, None, None, None)
     rows = []
     for i in range(n):
         name = C.create_string_buffer(128)
         fl, ms, cnt = C.c_double(), C.c_double(), C.c_int64()
         check(lib.vits_profile_read(i, name, 128, C.byref(fl), C.byref(ms), C.byref(cnt)), "profile_read")
-        rows.append(dict(name=name.value.decode(), flops=fl.value, ms=ms.value, count=cnt.value))
+        by = C.c_double()
+        check(lib.vits_profile_read_bytes(i, C.byref(by)), "profile_read_bytes")
+        rows.append(dict(name=name.value.decode(), flops=fl.value, ms=ms.value, count=cnt.value, bytes=by.value))
     return rows

@@ -74,6 +74,7 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
 struct ProfRow {
   std::string name;      // kernel instantiation, e.g. conv_mfma_kernel<2,2,1,4,0> = <WM,WN,WGM,WGN,MODE>
   double flops, ms;      // algorithmic FLOPs (2*rows*cin*taps*L*B) and summed event time
+  double bytes;          // algorithmic HBM bytes: input + output (+ residual, + accumulated output) + packed weights
   long long count;
 };
 void prof_enable(bool on);

@@ -23,6 +23,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -33,7 +34,7 @@ namespace vits {
 // ---- optional per-kernel timing (HIP events on the launch stream), off by default ----
 namespace {
 struct ProfClass {
-  double flops = 0.0, ms = 0.0;
+  double flops = 0.0, ms = 0.0, bytes = 0.0;
   long long count = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
@@ -83,7 +84,7 @@ int prof_collect(std::vector<ProfRow>& rows) {
       g_event_pool.push_back(p.second);
     }
     c.pending.clear();
-    rows.push_back(ProfRow{kv.first, c.flops, c.ms, c.count});
+    rows.push_back(ProfRow{kv.first, c.flops, c.ms, c.bytes, c.count});
   }
   return (int)rows.size();
 }
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 template <typename Launch>
-static hipError_t timed_launch(const char* name, const ConvArgs& a, hipStream_t stream, Launch&& launch) {
+static hipError_t timed_launch(const char* name, bool gate, const ConvArgs& a, hipStream_t stream, Launch&& launch) {
   if (!g_prof_on) {
     launch();
     return hipGetLastError();
@@ -832,6 +833,12 @@ static hipError_t timed_launch(const char* name, const ConvArgs& a, hipStream_t 
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfClass& c = g_prof[name];
     c.flops += 2.0 * a.M * a.Cin * a.K * (double)a.L * a.B;     // algorithmic: dense over every position
+    // every input and output element once, fp32: rows * L outputs (half of that after the gate), residual and
+    // accumulated-output reads where the epilogue has them, the packed weights once
+    const double outs = (gate ? 0.5 : 1.0) * a.M;
+    const int reads = ((a.flags & (F_RES | F_RES_SUB)) ? 1 : 0) + ((a.flags & F_ACCUM) ? 1 : 0);
+    const double wbytes = strstr(name, "conv_mfma") ? 4.0 : strstr(name, "conv_bf16_kernel") ? 2.0 : 6.0;
+    c.bytes += 4.0 * (double)a.L * a.B * (a.Cin + outs * (1 + reads)) + wbytes * a.M * a.Cin * a.K;
     c.count += 1;
     c.pending.emplace_back(e0, e1);
   }
@@ -848,7 +855,7 @@ static hipError_t launch_f32(ConvArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)CI_CHUNK * a.rs * sizeof(float);
   char name[96];
   snprintf(name, sizeof name, "conv_mfma_kernel<%d,%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE, (int)VEC);
-  return timed_launch(name, a, stream, [&] {
+  return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE, VEC>), grid, dim3(256), lds, stream, a);
   });
 }
@@ -863,7 +870,7 @@ static hipError_t launch_b3(ConvArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)6 * a.rs * sizeof(uint4);
   char name[96];
   snprintf(name, sizeof name, "conv_bf16x3_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
-  return timed_launch(name, a, stream, [&] {
+  return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_bf16x3_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
   });
 }
@@ -878,7 +885,7 @@ static hipError_t launch_b1(ConvArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * a.rs * sizeof(uint4);
   char name[96];
   snprintf(name, sizeof name, "conv_bf16_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
-  return timed_launch(name, a, stream, [&] {
+  return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
   });
 }
@@ -1133,7 +1140,7 @@ static hipError_t launch_b3ks(ConvArgs& a, hipStream_t stream) {
   const size_t lds = stage > red ? stage : red;
   char name[96];
   snprintf(name, sizeof name, "conv_b3ks_kernel<%d,%d>", WN, MODE);
-  return timed_launch(name, a, stream, [&] {
+  return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_b3ks_kernel<WN, MODE>), grid, dim3(256), lds, stream, a);
   });
 }

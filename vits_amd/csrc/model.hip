@@ -729,6 +729,14 @@ int vits_profile_read(int index, char* name, int name_len, double* flops, double
   return VITS_OK;
 }
 
+int vits_profile_read_bytes(int index, double* bytes) {
+  std::vector<ProfRow> rows;
+  const int n = prof_collect(rows);
+  if (index < 0 || index >= n || !bytes) return fail(VITS_ERR_INVALID, "profile_read_bytes: bad index");
+  *bytes = rows[index].bytes;
+  return VITS_OK;
+}
+
 // ---- single operators ----
 int vits_op_conv1d(const void* w, const float* bias, int cin, int rows, int taps, int dilation, int mode, int precision,
                    const float* x, int B, int L, const int* lengths, const float* cbias, const float* in_cbias,
