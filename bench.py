@@ -10,7 +10,8 @@ collective on the data path, weak scaling).  Rank 0 prints one JSON line:
   value      = audio-seconds synthesised per wall-second, summed over ranks (max-over-ranks time)
   roofline   = the dominant kernel (the MFMA conv instantiation with the largest summed time) timed with HIP events on
                its launch stream; algorithmic fp32 FLOP/s against the dense MFMA peak of the mode it runs in
-               (fp32 MFMA: 157.3 TFLOP/s; bf16x3: six bf16 products per fp32 product, 2500 / 6 = 416.7 TFLOP/s)
+               (fp32 MFMA: 157.3 TFLOP/s; f16x2: three fp16 products per fp32 product, 2500 / 3 = 833.3 TFLOP/s;
+               bf16x3: six bf16 products, 2500 / 6 = 416.7 TFLOP/s)
   cpu_baseline = the CPU oracle (a PyTorch fp32 port of the reference's infer) timed on this host's cores on a
                  bounded sample of the same workload
 """
@@ -30,6 +31,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 matrix peak
 PEAK_HBM_GBPS = 8000.0             # MI355X HBM3E
 # bf16x3 kernels spend six bf16 MFMA products per algorithmic fp32 product
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# f16x2 kernels spend three fp16 MFMA products (same dense rate as bf16) per algorithmic fp32 product
+PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 
 
 def build_model(device, precision=None):
@@ -153,8 +156,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--frames", type=int, default=258, help="frames per utterance (C2: 258; C3: 861 with --batch 64)")
     ap.add_argument("--phonemes", type=int, default=50, help="phonemes per utterance (C2: 50; C3: 160)")
-    ap.add_argument("--precision", choices=("fp32", "bf16x3", "bf16"), default=None,
-                    help="conv arithmetic: bf16x3 (default) and fp32 are fp32-grade (the C2 parity workload); bf16 runs "
+    ap.add_argument("--precision", choices=("fp32", "bf16x3", "f16x2", "bf16"), default=None,
+                    help="conv arithmetic: f16x2 (default), bf16x3 and fp32 are fp32-grade (the C2 parity workload); bf16 runs "
                          "the generator's convs in plain bf16 (BASELINE configs[2]: --batch 64 --frames 861 "
                          "--phonemes 160 --precision bf16)")
     ap.add_argument("--workload", choices=("batch", "c4"), default="batch",
@@ -230,7 +233,8 @@ def main():
         conv_ms = sum(r["ms"] for r in rows)
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         peak = (PEAK_FP32_MFMA_TFLOPS if dom["name"].startswith("conv_mfma_kernel") else
-                PEAK_BF16_MFMA_TFLOPS if dom["name"].startswith("conv_bf16_kernel") else PEAK_BF16X3_TFLOPS)
+                PEAK_BF16_MFMA_TFLOPS if dom["name"].startswith("conv_bf16_kernel") else
+                PEAK_F16X2_TFLOPS if dom["name"].startswith("conv_f16x2_kernel") else PEAK_BF16X3_TFLOPS)
         gbps = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
         # the bound is whichever roof the kernel's arithmetic intensity puts lower: the plain-bf16 generator layers
         # (64 / 32 channels) sit under the HBM roof, the fp32-grade modes under the MFMA roof

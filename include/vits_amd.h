@@ -54,7 +54,9 @@ int vits_model_set_tensor(vits_model* m, const char* name, const float* dev_ptr,
  * mode: 0 plain, 1 gated (tanh*sigmoid halves), 2/3/4 transposed conv with stride 8/4/2.
  * precision: 0 = fp32 MFMA on fp32-packed weights; 1 = three-term bf16 split ("bf16x3": both operands are split
  *   exactly into three bf16 terms, six cross products on the bf16 MFMA, fp32 accumulate; fp32-grade results) on
- *   weights packed by vits_pack_conv_weight_bf16x3; 2 = plain bf16 (both operands rounded to nearest-even bf16, one
+ *   weights packed by vits_pack_conv_weight_bf16x3; 3 = two-term fp16 split ("f16x2": x = h + l in fp16, three cross
+ *   products on the fp16 MFMA, fp32 accumulate; about 2^-22 relative error per product, operands must lie inside the
+ *   fp16 range, activations are clamped to +-65504) on weights packed by vits_pack_conv_weight_f16x2; 2 = plain bf16 (both operands rounded to nearest-even bf16, one
  *   product per multiply-accumulate, fp32 accumulate; about 8e-3 waveform max-abs against fp32 when used for the
  *   generator) on weights packed by vits_pack_conv_weight_bf16.
  * rows = packed GEMM rows (cout, or cout*stride for a transposed conv); bias has `rows` entries or is NULL. */
@@ -68,6 +70,9 @@ int vits_model_finalize(vits_model* m);
 int vits_pack_conv_weight(const float* host_w, int rows, int cin, int taps, float* host_out);
 /* Same for the bf16x3 mode: host_out gets 3*rows*cin*taps uint16 (bf16 bit patterns). */
 int vits_pack_conv_weight_bf16x3(const float* host_w, int rows, int cin, int taps, uint16_t* host_out);
+/* Same for the f16x2 mode: host_out gets 2*rows*cin*taps uint16 (fp16 bit patterns); fails if a weight is outside
+ * the fp16 range. */
+int vits_pack_conv_weight_f16x2(const float* host_w, int rows, int cin, int taps, uint16_t* host_out);
 /* Same for the plain bf16 mode: host_out gets rows*cin*taps uint16 (bf16 bit patterns, round to nearest even). */
 int vits_pack_conv_weight_bf16(const float* host_w, int rows, int cin, int taps, uint16_t* host_out);
 

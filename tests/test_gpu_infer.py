@@ -119,12 +119,16 @@ def test_infer_c3_fullsize_properties(gpu_model):
     assert torch.equal(o, o2)
 
 
-def test_infer_exact_fp32_mode(synthetic_sd):
-    """precision="fp32" (v_mfma_f32_32x32x2_f32 kernels) end to end against the reference goldens."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])
+def test_infer_fp32_grade_modes(synthetic_sd, precision):
+    """Every fp32-grade conv mode end to end against the reference goldens at the fp32 tolerances: "fp32"
+    (v_mfma_f32_32x32x2_f32), "bf16x3" (three-term bf16 splits, six products) and "f16x2" (two-term fp16 splits,
+    three products in the generator; the default, so every other test in this file runs it too)."""
     from vits_amd import SynthesizerTrn
     cfg = synthetic.ModelConfig()
     net = SynthesizerTrn(cfg.n_vocab, cfg.spec_channels, cfg.hop_length, cfg.sampling_rate, cfg.segment_size,
-                         precision="fp32", **cfg.kwargs()).eval()
+                         precision=precision, **cfg.kwargs()).eval()
+    assert net.precision == precision
     net.load_state_dict(synthetic_sd)
     for name in ("ragged_b2", "tensor_controls"):
         d, meta = load_case(name)

@@ -22,10 +22,10 @@ def dev(t):
     return None if t is None else t.cuda().contiguous()
 
 
-PREC = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+PREC = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3}
 
 
-@pytest.fixture(params=["fp32", "bf16x3", "bf16"])
+@pytest.fixture(params=["fp32", "bf16x3", "bf16", "f16x2"])
 def prec(request):
     return PREC[request.param]
 

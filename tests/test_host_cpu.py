@@ -79,6 +79,34 @@ def test_pack_bf16_planes():
     assert torch.equal(three[0].float(), one.float())
 
 
+def test_pack_f16x2_planes():
+    """fp16 fragment order [cin/16][taps][rows/32][2 planes][64 lanes][8]: h = fp16(w), l = fp16(w - h), both round to
+    nearest even with subnormals kept, so h + l reproduces w to 2^-22 relative (2^-25 absolute below 1/2); a weight
+    outside the fp16 range is refused."""
+    torch.manual_seed(3)
+    rows, cin, taps = 32, 16, 2
+    w = torch.randn(rows, cin, taps) * 0.05
+    w[0, 0, 0] = 3.0e-6                     # h is an fp16 subnormal
+    w[1, 0, 0] = 1000.123
+    packed = weights.pack_rows(w, N.PREC_F16X2)
+    f = packed.view(torch.float16).reshape(cin // 16, taps, rows // 32, 2, 64, 8).double()
+    got = torch.zeros(2, rows, cin, taps, dtype=torch.float64)
+    for lane in range(64):
+        for j in range(8):
+            for p_ in range(2):
+                got[p_, lane & 31, 8 * (lane >> 5) + j, :] = f[0, :, 0, p_, lane, j]
+    h, l = got
+    assert torch.equal(h.float(), w.to(torch.float16).float())
+    assert torch.equal(l.float(), (w - w.to(torch.float16).float()).to(torch.float16).float())
+    err = (h + l - w.double()).abs()
+    assert float((err / w.double().abs().clamp_min(0.5)).max()) <= 2.0 ** -22
+    assert float(err[w.abs() < 0.5].max()) <= 2.0 ** -25
+    bad = w.clone()
+    bad[2, 3, 1] = 7.0e4
+    with pytest.raises(RuntimeError):
+        weights.pack_rows(bad, N.PREC_F16X2)
+
+
 def emulate_transposed(w_rows, bias_rows, mode, x, up):
     """What the conv kernel computes for a transposed conv: GEMM rows with per-class tap offsets, then the
     row -> (channel, phase) scatter of its epilogue."""
@@ -124,6 +152,9 @@ def test_prepare_covers_every_used_key(synthetic_sd):
     pb = weights.prepare(synthetic_sd, cfg, N.PREC_BF16)
     assert {v[7] for k, v in pb.convs.items() if k.startswith("dec.")} == {N.PREC_BF16}
     assert {v[7] for k, v in pb.convs.items() if not k.startswith("dec.")} == {N.PREC_BF16X3}
+    ph = weights.prepare(synthetic_sd, cfg, N.PREC_F16X2)
+    assert {v[7] for k, v in ph.convs.items() if k.startswith("dec.")} == {N.PREC_F16X2}
+    assert {v[7] for k, v in ph.convs.items() if not k.startswith("dec.")} == {N.PREC_BF16X3}
     assert pw.plain["cond.w"].numel() == (3 * 192 + 512 + 4 * 1536) * 256
 
 

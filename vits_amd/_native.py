@@ -51,6 +51,7 @@ def _load():
         "vits_pack_conv_weight": (i32, [vp, i32, i32, i32, vp]),
         "vits_pack_conv_weight_bf16x3": (i32, [vp, i32, i32, i32, vp]),
         "vits_pack_conv_weight_bf16": (i32, [vp, i32, i32, i32, vp]),
+        "vits_pack_conv_weight_f16x2": (i32, [vp, i32, i32, i32, vp]),
         "vits_cond_rows": (i32, [vp]),
         "vits_speaker_cond": (i32, [vp, vp, i32, vp, vp, vp]),
         "vits_encoder_workspace_bytes": (i64, [vp, i32, i32]),
@@ -85,8 +86,8 @@ def _load():
 lib, EXPORTED = _load()
 
 MODE_PLAIN, MODE_GATE, MODE_UP8, MODE_UP4, MODE_UP2 = 0, 1, 2, 3, 4
-PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
-PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16X2 = 0, 1, 2, 3
+PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16x2": PREC_F16X2}
 F_IN_LRELU, F_IN_MASK, F_RELU, F_MASK_PRE, F_RES, F_RES_SUB, F_ACCUM, F_MASK_POST = (1 << i for i in range(8))
 
 

@@ -21,6 +21,7 @@ enum ConvMode : int {
 enum ConvPrec : int {
   PREC_F32    = 0,   // v_mfma_f32_32x32x2_f32, packed fp32 weights
   PREC_BF16X3 = 1,   // three-term bf16 split of both operands on v_mfma_f32_32x32x16_bf16 (fp32-grade results)
+  PREC_F16X2  = 3,   // two-term fp16 split of both operands, three products on v_mfma_f32_32x32x16_f16 (2^-22 relative)
   PREC_BF16   = 2,   // operands rounded to bf16, one product per MAC on v_mfma_f32_32x32x16_bf16, fp32 accumulate
 };
 
@@ -40,7 +41,8 @@ constexpr int MAX_TAPS = 12;
 constexpr int MAX_HALO = 64;    // max (max_off - min_off) a tile may need
 
 struct ConvDesc {          // one packed convolution, immutable after load
-  const void* w = nullptr;       // PREC_F32: fp32 [Cin/16][K][2][M/32][64][4]; PREC_BF16X3: bf16 [Cin/16][K][M/32][3][64][8]; PREC_BF16: bf16 [Cin/16][K][M/32][64][8]
+  const void* w = nullptr;       // PREC_F32: fp32 [Cin/16][K][2][M/32][64][4]; PREC_BF16X3: bf16 [Cin/16][K][M/32][3][64][8]; PREC_BF16: bf16 [Cin/16][K][M/32][64][8];
+                                 // PREC_F16X2: fp16 [Cin/16][K][M/32][2][64][8]
   int prec = PREC_F32;
   const float* bias = nullptr;   // [M] per-row bias, may be null
   int Cin = 0, M = 0, K = 0, mode = MODE_PLAIN;

@@ -13,11 +13,14 @@
 //   The next channel chunk is prefetched into registers while the current chunk is multiplied.
 //   C/D: column = time = lane & 31, so every accumulator register stores 128 contiguous bytes per half wave.
 //
-// Three arithmetic modes share tiling, prologue and epilogue:
+// Four arithmetic modes share tiling, prologue and epilogue:
 //   PREC_F32     v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (64 FLOP/clk/SIMD).
 //   PREC_BF16X3  every fp32 operand is split exactly into three bf16 terms (x = h + m + l, 24 significant bits) and
 //                the six largest cross products (hh, hm, mh, hl, lh, mm) run on v_mfma_f32_32x32x16_bf16 with fp32
 //                accumulation: fp32-grade results (dropped terms < 2^-24 relative) at 16/6 of the fp32 MFMA rate.
+//   PREC_F16X2   every fp32 operand is split into two fp16 terms (22 significant bits) and the three largest cross
+//                products run on v_mfma_f32_32x32x16_f16: half the matrix work of PREC_BF16X3, relative error per
+//                product about 2^-22; operands must lie inside the fp16 range.
 //   PREC_BF16    both operands rounded to bf16, one product, fp32 accumulation (8 significant bits per operand).
 #include "common.h"
 
@@ -811,6 +814,180 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// PREC_F16X2 kernel: every fp32 operand is split into two fp16 terms, x = h + l with h = fp16(x) and
+// l = fp16(x - h) (22 significant bits; fp16 subnormals are produced by the conversions and honoured by the MFMA, so
+// the absolute representation error is at most 2^-25 for |x| < 1/2), and the three largest cross products
+// (h*l, h*h, l*h) run on v_mfma_f32_32x32x16_f16 with fp32 accumulation: half the matrix work of the bf16x3 split for
+// a relative error per product of about 2^-22 instead of 2^-24.  Activations are clamped to the fp16 range
+// (+-65504) at staging.  Weights: [Cin/16][tap][M/32][2 planes][64 lanes][8 fp16]; LDS [2 planes][2 halves][ncols].
+// ---------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int WM, int WN, int WGM, int WGN, int MODE>
+__global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(const ConvArgs a) {
+  constexpr int BN = 32 * WN * WGN;
+  constexpr int NCT = (BN + MAX_HALO + 255) / 256;       // tile columns per thread
+  constexpr bool TWO_CLASS = (MODE == MODE_UP8 || MODE == MODE_UP2);
+  constexpr int NB = TWO_CLASS ? 2 : 1;
+  static_assert(WGM * WGN == 4, "four waves per block");
+  static_assert(!TWO_CLASS || WM == 2, "two-class transposed convs pair the classes in one wave");
+  static_assert(MODE != MODE_GATE || WM == 2, "gate pairs the tanh and sigmoid rows in one wave");
+
+  extern __shared__ __attribute__((aligned(16))) uint4 xq[];    // [2 planes][2 halves][ncols] of 8 fp16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int par = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BN;
+  const int len_b = a.lengths ? a.lengths[b] : 0x7fffffff;
+  const int ncols = a.rs;
+
+  int mt[WM];
+  bool mt_ok[WM];
+  wave_mtiles<WM, WGM, MODE>(a, wm, mt, mt_ok);
+
+  const float* xb = a.x + (long long)b * a.x_bs;
+  const int tstart = t0 + a.min_off;
+  const int wcols = a.width;
+  float st[NCT][16];
+  auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NCT; ++q) {
+      const int col = tid + 256 * q, t = tstart + col;
+      const bool ok = col < wcols && t >= 0 && t < a.L;
+      const float* xc = xb + (long long)chunk * 16 * a.x_cs + (ok ? t : 0);
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci) {
+        const float v = xc[(long long)ci * a.x_cs];
+        st[q][ci] = ok ? v : 0.f;
+      }
+    }
+  };
+  auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
+    const float* cbp = a.in_cbias ? a.in_cbias + (long long)b * a.in_cbias_bs + chunk * 16 : nullptr;
+#pragma unroll
+    for (int q = 0; q < NCT; ++q) {
+      const int col = tid + 256 * q, t = tstart + col;
+      if (col < wcols) {
+        bool ok = t >= 0 && t < a.L;
+        if (a.flags & F_IN_MASK) ok = ok && t < len_b;
+        unsigned ph[8], pl[8];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+          f32x2 v;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int ci = 2 * c2 + u;
+            float e = (st[q][ci] + (cbp ? cbp[ci] : 0.f)) * a.in_scale;
+            if (a.flags & F_IN_LRELU) e = fmaxf(e, e * a.in_slope);
+            e = fminf(fmaxf(e, -65504.f), 65504.f);
+            v[u] = ok ? e : 0.f;
+          }
+          const f16x2 h = __builtin_convertvector(v, f16x2);
+          const f32x2 r = v - __builtin_convertvector(h, f32x2);
+          const f16x2 l = __builtin_convertvector(r, f16x2);
+          ph[c2] = __builtin_bit_cast(unsigned, h);
+          pl[c2] = __builtin_bit_cast(unsigned, l);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          xq[(0 * 2 + hf) * ncols + col] = make_uint4(ph[4 * hf], ph[4 * hf + 1], ph[4 * hf + 2], ph[4 * hf + 3]);
+          xq[(1 * 2 + hf) * ncols + col] = make_uint4(pl[4 * hf], pl[4 * hf + 1], pl[4 * hf + 2], pl[4 * hf + 3]);
+        }
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // weight fragments: index (((chunk*K + tap) * mt_total + mt) * 2 + plane) * 64 + lane, in 16-byte units
+  const uint4* w16 = reinterpret_cast<const uint4*>(a.w);
+  const uint4* wp[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) wp[i] = w16 + (long long)mt[i] * 128 + lane;
+  const long long it_stride = (long long)a.mt_total * 128;
+  const int nchunks = a.Cin / 16;
+  const int n_it = nchunks * a.K;
+  uint4 A[2][WM], An[2][WM];      // planes h, l of the current and of the next tap
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) A[p][i] = wp[i][p * 64];
+  int it = 0;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  auto mma = [&](const uint4 (&af)[WM], const uint4 (&bf)[NB][WN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]),
+                                                           __builtin_bit_cast(f16x8, bf[TWO_CLASS ? i : 0][j]),
+                                                           acc[i][j], 0, 0, 0);
+  };
+
+  const int colbase = wn * WN * 32 + l31 + par * ncols - a.min_off;
+  uint4 B[2][NB][WN];             // planes h, l of the current tap
+  auto ldb = [&](int p, const int (&off)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) B[p][c][j] = xq[p * 2 * ncols + off[c] + j * 32];
+  };
+  // The next tap's weight fragments (L2) are requested at the top of a tap into a second register set; each
+  // activation plane (LDS) is refetched right after its last use.  All reloads are unconditional (a chunk's last tap
+  // re-reads its own activation fragments, the last tap of all its own weights): straight-line code, exact waits.
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+    int boff[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) boff[c] = colbase + a.toff0[c];
+    ldb(0, boff);
+    ldb(1, boff);
+    for (int k = 0; k < a.K; ++k) {
+      ++it;
+      const long long nxt = (long long)(it < n_it ? it : n_it - 1) * it_stride;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) An[p][i] = wp[i][nxt + p * 64];
+      int boffn[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) boffn[c] = k + 1 < a.K ? boff[c] + a.tstep[c] : boff[c];
+      mma(A[0], B[1]);                                   // h * l
+      ldb(1, boffn);
+      mma(A[0], B[0]);                                   // h * h
+      mma(A[1], B[0]);                                   // l * h
+      ldb(0, boffn);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) A[p][i] = An[p][i];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) boff[c] = boffn[c];
+    }
+    if (chunk + 1 < nchunks) {
+      __syncthreads();
+      store_chunk(chunk + 1);
+      __syncthreads();
+    }
+  }
+
+  conv_epilogue<WM, WN, MODE, true>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 template <typename Launch>
@@ -837,7 +1014,8 @@ static hipError_t timed_launch(const char* name, bool gate, const ConvArgs& a, h
     // accumulated-output reads where the epilogue has them, the packed weights once
     const double outs = (gate ? 0.5 : 1.0) * a.M;
     const int reads = ((a.flags & (F_RES | F_RES_SUB)) ? 1 : 0) + ((a.flags & F_ACCUM) ? 1 : 0);
-    const double wbytes = strstr(name, "conv_mfma") ? 4.0 : strstr(name, "conv_bf16_kernel") ? 2.0 : 6.0;
+    const double wbytes = strstr(name, "conv_mfma") || strstr(name, "conv_f16x2") ? 4.0
+                          : strstr(name, "conv_bf16_kernel") ? 2.0 : 6.0;
     c.bytes += 4.0 * (double)a.L * a.B * (a.Cin + outs * (1 + reads)) + wbytes * a.M * a.Cin * a.K;
     c.count += 1;
     c.pending.emplace_back(e0, e1);
@@ -887,6 +1065,21 @@ static hipError_t launch_b1(ConvArgs& a, hipStream_t stream) {
   snprintf(name, sizeof name, "conv_bf16_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
   return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
+  });
+}
+
+template <int WM, int WN, int WGM, int WGN, int MODE>
+static hipError_t launch_h2(ConvArgs& a, hipStream_t stream) {
+  constexpr int BN = 32 * WN * WGN;
+  a.width = BN + (a.width);
+  a.rs = a.width;                    // columns per (plane, half) slab
+  const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + WM - 1) / WM;
+  dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
+  const size_t lds = (size_t)4 * a.rs * sizeof(uint4);
+  char name[96];
+  snprintf(name, sizeof name, "conv_f16x2_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
+  return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
+    hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
   });
 }
 
@@ -1173,6 +1366,7 @@ template <int WM, int WN, int WGM, int WGN, int MODE>
 static hipError_t launch_cfg(ConvArgs& a, int prec, hipStream_t stream) {
   if (prec == PREC_BF16X3) return launch_b3<WM, WN, WGM, WGN, MODE>(a, stream);
   if (prec == PREC_BF16) return launch_b1<WM, WN, WGM, WGN, MODE>(a, stream);
+  if (prec == PREC_F16X2) return launch_h2<WM, WN, WGM, WGN, MODE>(a, stream);
   // dwordx4 staging needs 16-byte aligned rows and whole groups of four time steps
   const bool vec = a.L % 4 == 0 && a.x_cs % 4 == 0 && a.x_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
   if (vec) return launch_f32<WM, WN, WGM, WGN, MODE, true>(a, stream);

@@ -107,7 +107,7 @@ int make_desc(ConvDesc& d, const void* w, const float* bias, int cin, int rows, 
   d.M = rows;
   d.K = taps;
   d.mode = mode;
-  if (prec != PREC_F32 && prec != PREC_BF16X3 && prec != PREC_BF16) return fail(VITS_ERR_INVALID, "conv: unknown precision");
+  if (prec != PREC_F32 && prec != PREC_BF16X3 && prec != PREC_BF16 && prec != PREC_F16X2) return fail(VITS_ERR_INVALID, "conv: unknown precision");
   d.prec = prec;
   switch (mode) {
     case MODE_PLAIN:
@@ -464,6 +464,31 @@ int vits_pack_conv_weight_bf16(const float* w, int rows, int cin, int taps, uint
             const int ci = chunk * 16 + 8 * (lane >> 5) + j;
             out[o++] = f2bf(w[((int64_t)row * cin + ci) * taps + k]);
           }
+  return VITS_OK;
+}
+
+int vits_pack_conv_weight_f16x2(const float* w, int rows, int cin, int taps, uint16_t* out) {
+  if (!w || !out || rows <= 0 || rows % 32 || cin <= 0 || cin % 16 || taps < 1)
+    return fail(VITS_ERR_INVALID, "pack: rows % 32 == 0 and cin % 16 == 0 required");
+  // [cin/16][taps][rows/32][2 planes][64 lanes][8]: h = fp16(w), l = fp16(w - h), round to nearest even, subnormals kept
+  const int mt_total = rows / 32, nchunks = cin / 16;
+  int64_t o = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk)
+    for (int k = 0; k < taps; ++k)
+      for (int mt = 0; mt < mt_total; ++mt) {
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int row = mt * 32 + (lane & 31);
+            const int ci = chunk * 16 + 8 * (lane >> 5) + j;
+            const float v = w[((int64_t)row * cin + ci) * taps + k];
+            if (!(std::fabs(v) <= 65504.f)) return fail(VITS_ERR_INVALID, "pack_f16x2: weight outside the fp16 range");
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            std::memcpy(&out[o + (0 * 64 + lane) * 8 + j], &h, 2);
+            std::memcpy(&out[o + (1 * 64 + lane) * 8 + j], &l, 2);
+          }
+        o += 2 * 64 * 8;
+      }
   return VITS_OK;
 }
 

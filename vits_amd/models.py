@@ -33,9 +33,11 @@ class SynthesizerTrn:
             raise NotImplementedError("only resblock='1' (ResBlock1) is implemented; the reference config uses it")
         if n_speakers <= 1 or gin_channels <= 0:
             raise NotImplementedError("a speaker-conditioned model (n_speakers > 1, gin_channels > 0) is required")
-        # arithmetic of the conv kernels: "bf16x3" (default) and "fp32" give fp32-grade results; "bf16" runs the
-        # generator's convs in plain bf16 (fp32 accumulate).  Keyword `precision` or env VITS_PRECISION
-        prec = kwargs.pop("precision", None) or os.environ.get("VITS_PRECISION", "bf16x3")
+        # arithmetic of the conv kernels.  fp32-grade: "f16x2" (default: the generator's convs as three fp16 products
+        # of two-term operand splits, everything else bf16x3), "bf16x3" (six bf16 products of three-term splits; full
+        # fp32 range) and "fp32" (fp32 MFMA).  "bf16": generator convs in plain bf16, fp32 accumulate.
+        # Keyword `precision` or env VITS_PRECISION
+        prec = kwargs.pop("precision", None) or os.environ.get("VITS_PRECISION", "f16x2")
         if prec not in N.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(N.PRECISIONS)}")
         self.precision = prec

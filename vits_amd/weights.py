@@ -40,6 +40,10 @@ def pack_rows(w_rows: torch.Tensor, precision: int = N.PREC_F32) -> torch.Tensor
         out = torch.empty(3 * rows * cin * taps, dtype=torch.int16)
         N.check(N.lib.vits_pack_conv_weight_bf16x3(w_rows.data_ptr(), rows, cin, taps, out.data_ptr()), "pack_bf16x3")
         return out
+    if precision == N.PREC_F16X2:
+        out = torch.empty(2 * rows * cin * taps, dtype=torch.int16)
+        N.check(N.lib.vits_pack_conv_weight_f16x2(w_rows.data_ptr(), rows, cin, taps, out.data_ptr()), "pack_f16x2")
+        return out
     if precision == N.PREC_BF16:
         out = torch.empty(rows * cin * taps, dtype=torch.int16)
         N.check(N.lib.vits_pack_conv_weight_bf16(w_rows.data_ptr(), rows, cin, taps, out.data_ptr()), "pack_bf16")
@@ -102,14 +106,15 @@ class PreparedWeights:
     """CPU-side result of preparing a checkpoint: plain tensors and packed convs keyed by library names."""
 
     def __init__(self, precision: int = N.PREC_F32):
-        # model-level mode.  PREC_BF16 means: the generator's convs ("dec.*", 97 % of the FLOPs) in plain bf16, every
-        # conv upstream of the latent z in bf16x3, so durations, masks and latents are those of the fp32-grade modes
+        # model-level mode.  PREC_BF16 / PREC_F16X2 apply to the generator's convs ("dec.*", 97 % of the FLOPs); every
+        # conv upstream of the latent z then runs in bf16x3 (full fp32 range and 24 bits where durations, masks and
+        # latents are decided, and where the time is not)
         self.precision = precision
         self.plain: Dict[str, torch.Tensor] = {}
         self.convs: Dict[str, Tuple[torch.Tensor, torch.Tensor, int, int, int, int, int, int]] = {}
 
     def conv_precision(self, name: str) -> int:
-        if self.precision == N.PREC_BF16 and not name.startswith("dec."):
+        if self.precision in (N.PREC_BF16, N.PREC_F16X2) and not name.startswith("dec."):
             return N.PREC_BF16X3
         return self.precision
 
