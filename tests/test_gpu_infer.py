@@ -175,3 +175,34 @@ def test_infer_bf16_generator_mode(synthetic_sd):
         assert metrics.max_abs(o, ref) <= BF16_WAV_TOL
         assert float((o.cpu() - ref).pow(2).mean().sqrt()) <= 3e-3          # measured 1e-3
         assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= BF16_MEL_TOL
+
+
+@pytest.mark.parametrize("chunk", [64, 50, 7])
+def test_infer_stream_concatenates_to_infer(gpu_model, chunk):
+    """Chunked synthesis (windows of `chunk` frames + the generator's receptive field as context) must reproduce the
+    whole-utterance waveform bit for bit: every output sample sees the same operands in the same order."""
+    b = synthetic.make_batch(11, [20, 14], [150, 117])            # ragged: the padded tail is part of the contract
+    kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
+    full = gpu_model.infer(b.phonemes, b.lengths, **kw)
+    st = gpu_model.infer_stream(b.phonemes, b.lengths, chunk_frames=chunk, **kw)
+    assert st.halo_frames == 13 and st.total_frames == 150
+    pieces, pos = [], 0
+    for start, wav in st:
+        assert start == pos and wav.shape[:2] == (2, 1)
+        pieces.append(wav.clone())
+        pos += wav.shape[-1]
+    assert pos == st.total_samples == full[0].shape[-1]
+    assert torch.equal(torch.cat(pieces, -1), full[0])
+    assert torch.equal(st.outputs[0], full[1]) and torch.equal(st.outputs[1][0], full[2][0])
+
+
+def test_infer_stream_max_len_and_single_window(gpu_model):
+    b = synthetic.make_batch(12, [9], [40])
+    kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
+    full = gpu_model.infer(b.phonemes, b.lengths, max_len=33, **kw)[0]
+    got = torch.cat([w for _, w in gpu_model.infer_stream(b.phonemes, b.lengths, max_len=33, chunk_frames=16, **kw)], -1)
+    assert got.shape == full.shape == (1, 1, 33 * 512) and torch.equal(got, full)
+    one = list(gpu_model.infer_stream(b.phonemes, b.lengths, chunk_frames=1000, **kw))
+    assert len(one) == 1 and torch.equal(one[0][1], gpu_model.infer(b.phonemes, b.lengths, **kw)[0])
+    with pytest.raises(ValueError):
+        gpu_model.infer_stream(b.phonemes, b.lengths, chunk_frames=0, **kw)

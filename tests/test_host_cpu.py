@@ -167,3 +167,14 @@ def test_hparams_and_config_reader(tmp_path):
     assert hps.model.url == "http://x/y"
     p.write_text(json.dumps({"a": {"b": 1}}))
     assert utils.get_hparams_from_file(str(p)).a.b == 1
+
+
+def test_generator_halo_frames():
+    """Receptive field of the generator in frames per side (what a streaming window needs as context): 13 for the
+    reference configuration (reference configs/config.json:140-160), wider kernels / dilations widen it."""
+    from vits_amd.models import generator_halo_frames
+    cfg = synthetic.ModelConfig()
+    assert generator_halo_frames(cfg) == 13
+    import dataclasses
+    wide = dataclasses.replace(cfg, resblock_kernel_sizes=(3, 7, 13))
+    assert generator_halo_frames(wide) > 13

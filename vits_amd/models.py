@@ -175,6 +175,38 @@ class SynthesizerTrn:
               pitch_control=None, duration_control=None, noise=None, stages: Optional[dict] = None):
         """reference models.py:717-767.  Extra keyword ``noise`` ([B, inter_channels, T]) replaces the
         torch.randn_like draw at :763; ``stages`` (a dict) receives stage-boundary tensors for tests."""
+        fe = self._frontend(phonemes, phonemes_lengths, sid, noise_scale, max_len, energy_control, pitch_control,
+                            duration_control, noise, stages)
+        B, T, t_dec, dev = fe["B"], fe["T"], fe["t_dec"], self.device
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            ws = self._workspace(N.lib.vits_generator_workspace_bytes(self._handle, B, t_dec))
+            o = torch.empty(B, 1, t_dec * self.total_upsample, dtype=torch.float32, device=dev)
+            N.check(N.lib.vits_generator(self._handle, fe["z"].data_ptr(), fe["totals"].data_ptr(), fe["cond"].data_ptr(),
+                                         B, T, t_dec, o.data_ptr(), ws.data_ptr(), ws.numel(), stream), "generator")
+        return (o,) + fe["outputs"]
+
+    @torch.no_grad()
+    def infer_stream(self, phonemes, phonemes_lengths, sid=None, noise_scale=1, max_len=None, energy_control=None,
+                     pitch_control=None, duration_control=None, noise=None, chunk_frames: int = 64):
+        """Chunked synthesis: everything up to the latent z runs once, then the generator runs on windows of
+        ``chunk_frames`` frames plus GENERATOR_HALO_FRAMES on each side and only the window's own samples are kept.
+        The halo covers the generator's receptive field (13 frames a side for the reference configuration), so the
+        chunks concatenate to exactly the waveform infer() returns, while the first audio is ready after one window
+        instead of the whole utterance.  The reference's callers synthesise whole utterances only
+        (reference inference_api.py:38-60).
+
+        Returns an InferStream: iterate it for (first_sample, wav[B, 1, n]) pairs; its ``outputs`` attribute holds the
+        rest of infer()'s tuple (x_mask, (z, z_p, m_p, logs_p), duration, F0, energy)."""
+        if chunk_frames <= 0:
+            raise ValueError("chunk_frames must be positive")
+        fe = self._frontend(phonemes, phonemes_lengths, sid, noise_scale, max_len, energy_control, pitch_control,
+                            duration_control, noise, None)
+        return InferStream(self, fe, int(chunk_frames))
+
+    def _frontend(self, phonemes, phonemes_lengths, sid, noise_scale, max_len, energy_control, pitch_control,
+                  duration_control, noise, stages):
+        """Everything of infer() before the generator: reference models.py:717-763."""
         if not self._ready:
             raise RuntimeError("no weights loaded: call load_state_dict / utils.load_checkpoint first")
         if sid is None:
@@ -272,8 +304,7 @@ class SynthesizerTrn:
             t_dec = len(range(T)[:max_len])
             if t_dec <= 0:
                 raise ValueError("max_len leaves no frames to decode")
-            need = max(lib.vits_encoder_workspace_bytes(h, B, T), lib.vits_flow_workspace_bytes(h, B, T),
-                       lib.vits_generator_workspace_bytes(h, B, t_dec))
+            need = max(lib.vits_encoder_workspace_bytes(h, B, T), lib.vits_flow_workspace_bytes(h, B, T))
             ws = self._workspace(need)
             stats = torch.empty(B, 2 * IC, T, **f32)
             z_p = torch.empty(B, IC, T, **f32)
@@ -285,9 +316,50 @@ class SynthesizerTrn:
                 stages["prior"] = x_frame.clone()
             N.check(lib.vits_flow_reverse(h, z.data_ptr(), totals.data_ptr(), cond.data_ptr(), B, T, ws.data_ptr(),
                                           ws.numel(), stream), "flow_reverse")
-            o = torch.empty(B, 1, t_dec * self.total_upsample, **f32)
-            N.check(lib.vits_generator(h, z.data_ptr(), totals.data_ptr(), cond.data_ptr(), B, T, t_dec, o.data_ptr(),
-                                       ws.data_ptr(), ws.numel(), stream), "generator")
             x_mask = (torch.arange(T, device=dev)[None, :] < totals[:, None]).unsqueeze(1)
             m_p, logs_p = stats[:, :IC], stats[:, IC:]
-        return o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy
+        return dict(B=B, T=T, t_dec=t_dec, z=z, totals=totals, cond=cond,
+                    outputs=(x_mask, (z, z_p, m_p, logs_p), duration, f0, energy))
+
+
+# Frames of context the generator needs on each side of a window for its output to equal that of the whole
+# utterance.  Walking back from the waveform through the reference configuration (reference models.py:257-303,
+# modules.py:183-225): conv_post 3 samples; each ResBlock stage 60 (kernel 11: (5+5) + (15+5) + (25+5)); a transposed
+# conv of stride s turns a reach of R output samples into ceil(R / s) + 1 input samples; conv_pre 3 frames:
+# 63 -> 33 -> 93 -> 25 -> 85 -> 12 -> 72 -> 10 -> 13 frames.  InferStream computes it from the model's own configuration.
+def generator_halo_frames(cfg) -> int:
+    reach = 3                                                     # conv_post, kernel 7
+    per_stage = max(sum((k - 1) * d // 2 + (k - 1) // 2 for d in dils)
+                    for k, dils in zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes))
+    for u in reversed(cfg.upsample_rates):
+        reach = -(-(reach + per_stage) // u) + 1
+    return reach + 3                                              # conv_pre, kernel 7
+
+
+class InferStream:
+    """Iterator over the waveform windows of one SynthesizerTrn.infer_stream call (see there)."""
+
+    def __init__(self, net: "SynthesizerTrn", fe: dict, chunk_frames: int):
+        self._net, self._fe, self.chunk_frames = net, fe, chunk_frames
+        self.halo_frames = generator_halo_frames(net.cfg)
+        self.outputs = fe["outputs"]
+        self.total_frames = fe["t_dec"]
+        self.total_samples = fe["t_dec"] * net.total_upsample
+
+    def __iter__(self):
+        net, fe = self._net, self._fe
+        lib, h, dev, up = N.lib, net._handle, net.device, net.total_upsample
+        B, T, t_dec, z, H = fe["B"], fe["T"], fe["t_dec"], fe["z"], self.halo_frames
+        with torch.no_grad(), torch.cuda.device(dev):
+            for s in range(0, t_dec, self.chunk_frames):
+                e = min(s + self.chunk_frames, t_dec)
+                s0, e0 = max(0, s - H), min(t_dec, e + H)          # window + context; the utterance's own ends stay
+                n = e0 - s0
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                ws = net._workspace(lib.vits_generator_workspace_bytes(h, B, n))
+                lens = (fe["totals"] - s0).clamp_(min=0)           # the length mask, relative to the window start
+                o = torch.empty(B, 1, n * up, dtype=torch.float32, device=dev)
+                # window of z: same row stride T, start shifted by s0 frames
+                N.check(lib.vits_generator(h, z.data_ptr() + 4 * s0, lens.data_ptr(), fe["cond"].data_ptr(), B, T, n,
+                                           o.data_ptr(), ws.data_ptr(), ws.numel(), stream), "generator (window)")
+                yield s * up, o[:, :, (s - s0) * up:(e - s0) * up]
