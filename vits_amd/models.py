@@ -108,7 +108,7 @@ class SynthesizerTrn:
             device = torch.device("cuda", torch.cuda.current_device())
         if device != self.device:
             self.device = device
-            if self._sd:
+            if self._sd or getattr(self, "_packed", None) is not None:
                 self._upload()
         return self
 
@@ -140,10 +140,30 @@ class SynthesizerTrn:
         self._upload()
         return self
 
-    def _upload(self):
+    @classmethod
+    def from_packed(cls, path: str, device=None) -> "SynthesizerTrn":
+        """Build a model from a file written by vits_amd.packed.save_packed (or `python -m vits_amd.packed`): the
+        configuration, the arithmetic mode and every folded, fragment-ordered tensor come from the file and go to the
+        GPU as they are.  state_dict() of such a model holds shapes only."""
+        from . import packed
+        cfg, precision, pw = packed.load_packed(path)
+        net = cls(cfg.n_vocab, cfg.spec_channels, cfg.hop_length, cfg.sampling_rate, cfg.segment_size,
+                  precision=precision, **cfg.kwargs())
+        if device is not None:
+            net.device = torch.device(device)
+            if net.device.index is None:
+                net.device = torch.device("cuda", torch.cuda.current_device())
+        net._packed = pw
+        net._upload(pw)
+        return net
+
+    def _upload(self, pw=None):
         if not torch.cuda.is_available():
             raise RuntimeError("vits_amd needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
-        pw = weights.prepare(self._sd, self.cfg, N.PRECISIONS[self.precision])
+        if pw is None:
+            pw = getattr(self, "_packed", None) if not self._sd else None
+        if pw is None:
+            pw = weights.prepare(self._sd, self.cfg, N.PRECISIONS[self.precision])
         self._device_tensors = []
         h = self._handle
         with torch.cuda.device(self.device):
@@ -320,6 +340,26 @@ class SynthesizerTrn:
             m_p, logs_p = stats[:, :IC], stats[:, IC:]
         return dict(B=B, T=T, t_dec=t_dec, z=z, totals=totals, cond=cond,
                     outputs=(x_mask, (z, z_p, m_p, logs_p), duration, f0, energy))
+
+
+def config_from_hparams(hps, n_vocab: int):
+    """ModelConfig from a reference config (utils.get_hparams_from_file) the way the reference's callers build the
+    model: SynthesizerTrn(len(symbols), filter_length // 2 + 1, hop_length, sampling_rate, segment_size // hop_length,
+    n_speakers=..., **hps.model) (reference inference.py:25-33)."""
+    model = dict(hps.model.items()) if hasattr(hps.model, "items") else dict(hps.model)
+    fields = {f.name for f in __import__("dataclasses").fields(synthetic.ModelConfig)}
+    kw = {k: v for k, v in model.items() if k in fields}
+    for k in ("resblock_kernel_sizes", "upsample_rates", "upsample_kernel_sizes"):
+        if k in kw:
+            kw[k] = tuple(kw[k])
+    if "resblock_dilation_sizes" in kw:
+        kw["resblock_dilation_sizes"] = tuple(tuple(d) for d in kw["resblock_dilation_sizes"])
+    if "resblock" in kw:
+        kw["resblock"] = str(kw["resblock"])
+    return synthetic.ModelConfig(n_vocab=n_vocab, spec_channels=hps.data.filter_length // 2 + 1,
+                                 hop_length=hps.data.hop_length, sampling_rate=hps.data.sampling_rate,
+                                 segment_size=hps.train.segment_size // hps.data.hop_length,
+                                 n_speakers=hps.data.n_speakers, **kw)
 
 
 # Frames of context the generator needs on each side of a window for its output to equal that of the whole
