@@ -81,6 +81,7 @@ struct ProfRow {
 };
 void prof_enable(bool on);
 bool prof_enabled();
+int device_cu_count();      // compute units of the current device (256 on MI355X), cached
 void prof_reset();
 int prof_collect(std::vector<ProfRow>& rows);
 

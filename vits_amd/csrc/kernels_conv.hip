@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const C
   }
 }
 
-static int device_cu_count() {
+int device_cu_count() {
   static const int n = [] {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;

@@ -265,16 +265,26 @@ hipError_t launch_attention(const float* qkv, const float* emb_k, const float* e
   if (DK != ATT_DK || window != ATT_W || B <= 0 || L <= 0 || L > 2048 || B > 65535) return hipErrorInvalidValue;
   const int nch = (L + 63) / 64;
 #define ATT_LAUNCH(N, Q) attention_launch<N, Q>(qkv, emb_k, emb_v, lengths, out, B, H, L, s)
-  // the score row lives in registers: QPW * NCH floats per lane, so longer rows take fewer queries per wave
-  if (nch <= 1) ATT_LAUNCH(1, 16);
-  else if (nch <= 2) ATT_LAUNCH(2, 16);
-  else if (nch <= 3) ATT_LAUNCH(3, 16);
-  else if (nch <= 5) ATT_LAUNCH(5, 16);
+  // The score row lives in registers: QPW * NCH floats per lane, so longer rows take fewer queries per wave.
+  // Short rows have a choice: 16, 8 or 4 queries per wave.  A block re-stages every key and value of its (batch, head),
+  // so fewer, larger blocks do less work, but phoneme-rate and batch-1 launches would leave most CUs idle: take the
+  // largest block that still gives two blocks per CU, else the smallest.
+  int qpw = 16;
+  if (nch <= 5) {
+    const long long per_row = (long long)H * B, want = 2LL * device_cu_count();
+    while (qpw > 4 && ((L + 4 * qpw - 1) / (4 * qpw)) * per_row < want) qpw >>= 1;
+  }
+#define ATT_PICK(N) (qpw == 16 ? ATT_LAUNCH(N, 16) : qpw == 8 ? ATT_LAUNCH(N, 8) : ATT_LAUNCH(N, 4))
+  if (nch <= 1) ATT_PICK(1);
+  else if (nch <= 2) ATT_PICK(2);
+  else if (nch <= 3) ATT_PICK(3);
+  else if (nch <= 5) ATT_PICK(5);
   else if (nch <= 8) ATT_LAUNCH(8, 8);
   else if (nch <= 12) ATT_LAUNCH(12, 8);
   else if (nch <= 16) ATT_LAUNCH(16, 4);
   else if (nch <= 24) ATT_LAUNCH(24, 4);
   else ATT_LAUNCH(32, 4);
+#undef ATT_PICK
 #undef ATT_LAUNCH
   return hipGetLastError();
 }
