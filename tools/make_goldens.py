@@ -115,6 +115,10 @@ def main():
         h.update(k.encode())
         h.update(v.numpy().tobytes())
     report = {"state_dict_sha256": h.hexdigest(), "cases": {}}
+    # digest of the reference's symbol inventory (text/symbols.py): pins the phoneme -> id order of vits_amd/text.py
+    from text.symbols import symbols as ref_symbols
+    report["symbols_sha256"] = hashlib.sha256("\n".join(ref_symbols).encode()).hexdigest()
+    report["n_symbols"] = len(ref_symbols)
 
     mk = synthetic.make_batch
     cases = {}
