@@ -120,6 +120,21 @@ int64_t vits_flow_workspace_bytes(const vits_model* m, int B, int T);
 int vits_flow_reverse(const vits_model* m, float* z, const int* frame_lengths, const float* cond, int B, int T,
                       void* ws, int64_t ws_bytes, void* stream);
 
+/* ResidualCouplingBlock.forward(reverse=False) (reference models.py:209-212, modules.py:320-335) in place on z: the
+ * z -> z_p direction used by voice conversion (models.py:774).  Same workspace as vits_flow_reverse. */
+int vits_flow_forward(const vits_model* m, float* z, const int* frame_lengths, const float* cond, int B, int T,
+                      void* ws, int64_t ws_bytes, void* stream);
+
+/* PosteriorEncoder.forward (reference models.py:243-250), available when the enc_q.* convs were registered
+ * ("enc_q.pre", "enc_q.in.N" gated, "enc_q.res.N", "enc_q.skip.N", "enc_q.proj"; their conditioning rows appended to
+ * cond.w / cond.b).  spec [B, vits_posterior_channels(m), T]: the linear spectrogram with its channel count rounded
+ * up to a multiple of 16, the added channels zero (the packed enc_q.pre weight is padded the same way).
+ * stats [B, 2*inter, T] receives (m_q, logs_q); z = (m_q + noise * exp(logs_q)) * mask. */
+int vits_posterior_channels(const vits_model* m);          /* -1 when the model has no posterior encoder */
+int64_t vits_posterior_workspace_bytes(const vits_model* m, int B, int T);
+int vits_posterior_encoder(const vits_model* m, const float* spec, const int* frame_lengths, const float* cond, int B,
+                           int T, const float* noise, float* stats, float* z, void* ws, int64_t ws_bytes, void* stream);
+
 /* Generator.forward (reference models.py:284-303) on (z * mask)[:, :, :t_dec]: z has row stride T;
  * wav [B, 1, t_dec * prod(upsample_rates)]. */
 int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec);

@@ -176,7 +176,9 @@ class OracleSynthesizer:
         H = x.shape[1]
         out = torch.zeros_like(x)
         gc = F.conv1d(g, w[p + ".cond_layer.weight"], w[p + ".cond_layer.bias"])
-        n = self.wn_layers
+        n = 0
+        while f"{p}.in_layers.{n}.weight" in w:                 # 4 layers in a flow, 16 in the posterior encoder
+            n += 1
         for i in range(n):
             wi = w[f"{p}.in_layers.{i}.weight"]
             x_in = F.conv1d(x, wi, w[f"{p}.in_layers.{i}.bias"], padding=(wi.shape[2] - 1) // 2)
@@ -203,6 +205,47 @@ class OracleSynthesizer:
             m = F.conv1d(h, w[p + ".post.weight"], w[p + ".post.bias"]) * mf
             z = torch.cat([x0, (x1 - m) * mf], 1)
         return z
+
+    def flow_forward(self, z, mf, g):
+        """reference models.py:209-212 (coupling then Flip, layers in order) and modules.py:320-335 (mean_only)."""
+        w = self.w
+        half = z.shape[1] // 2
+        for fid in self.flow_ids:
+            p = f"flow.flows.{fid}"
+            x0, x1 = z[:, :half], z[:, half:]
+            h = F.conv1d(x0, w[p + ".pre.weight"], w[p + ".pre.bias"]) * mf
+            h = self.wn(p + ".enc", h, mf, g)
+            m = F.conv1d(h, w[p + ".post.weight"], w[p + ".post.bias"]) * mf
+            z = torch.flip(torch.cat([x0, m + x1 * mf], 1), [1])
+        return z
+
+    # ------------------------------------------------------------------ voice conversion
+    def posterior_encoder(self, y, mf, g, noise):
+        """reference models.py:243-250: pre (1x1) -> WN (16 layers) -> proj; z = (m + eps * exp(logs)) * mask."""
+        w = self.w
+        x = F.conv1d(y, w["enc_q.pre.weight"], w["enc_q.pre.bias"]) * mf
+        x = self.wn("enc_q.enc", x, mf, g)
+        stats = F.conv1d(x, w["enc_q.proj.weight"], w["enc_q.proj.bias"]) * mf
+        m, logs = torch.chunk(stats, 2, dim=1)
+        return (m + noise * torch.exp(logs)) * mf, m, logs
+
+    @torch.no_grad()
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, noise: Optional[torch.Tensor] = None):
+        """reference models.py:769-777.  y: linear spectrogram [B, spec_channels, T]; ``noise`` replaces the
+        torch.randn_like draw of the posterior encoder (models.py:249)."""
+        w = self.w
+        g_src = w["emb_g.weight"][sid_src].unsqueeze(-1)
+        g_tgt = w["emb_g.weight"][sid_tgt].unsqueeze(-1)
+        y = y.to(torch.float32)
+        y_mask = sequence_mask(y_lengths, y.shape[2]).unsqueeze(1)
+        mf = y_mask.to(torch.float32)
+        if noise is None:
+            noise = torch.randn(y.shape[0], w["enc_q.proj.weight"].shape[0] // 2, y.shape[2])
+        z, m_q, logs_q = self.posterior_encoder(y, mf, g_src, noise)
+        z_p = self.flow_forward(z, mf, g_src)
+        z_hat = self.flow_reverse(z_p, mf, g_tgt)
+        o_hat = self.generator(z_hat * mf, g_tgt)
+        return o_hat, mf, (z, z_p, z_hat)
 
     # ------------------------------------------------------------------ generator
     def generator(self, x, g):

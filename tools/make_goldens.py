@@ -95,10 +95,41 @@ def to_np(v):
     return np.asarray(v)
 
 
+def make_vc(net, oracle, report):
+    """voice_conversion (reference models.py:769-777) on a ragged batch of synthetic spectrograms; the posterior
+    encoder's torch.randn_like draw is pinned by seeding right before the call."""
+    y, y_lengths = synthetic.make_spectrogram(31, [37, 29])
+    sid_src, sid_tgt = torch.tensor([5, 40]), torch.tensor([17, 3])
+    torch.manual_seed(2031)
+    with torch.no_grad():
+        o_hat, y_mask, (z, z_p, z_hat) = net.voice_conversion(y, y_lengths, sid_src, sid_tgt)
+    torch.manual_seed(2031)
+    noise = torch.randn(2, 192, 37)
+    oo, omask, (oz, ozp, ozh) = oracle.voice_conversion(y, y_lengths, sid_src, sid_tgt, noise=noise)
+    errs = {"o_hat": metrics.max_abs(oo, o_hat), "z": metrics.max_abs(oz, z), "z_p": metrics.max_abs(ozp, z_p),
+            "z_hat": metrics.max_abs(ozh, z_hat)}
+    assert torch.equal(omask, y_mask)
+    report["cases"]["vc"] = dict(oracle_vs_reference_max_abs=errs, wav_std=float(o_hat.std()),
+                                 wav_absmax=float(o_hat.abs().max()), frames=[37, 29])
+    print("vc", json.dumps(report["cases"]["vc"]))
+    np.savez_compressed(os.path.join(OUT, "vc.npz"), in_sid_src=to_np(sid_src), in_sid_tgt=to_np(sid_tgt),
+                        in_noise=to_np(noise), out_o_hat=to_np(o_hat), out_y_mask=to_np(y_mask), out_z=to_np(z),
+                        out_z_p=to_np(z_p), out_z_hat=to_np(z_hat))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cfg = synthetic.ModelConfig()
     net, hps = load_reference()
+    if "--vc-only" in sys.argv:          # add / refresh the voice-conversion vectors without touching the others
+        sd = synthetic.synthetic_state_dict(cfg)
+        net.load_state_dict(sd, strict=True)
+        path = os.path.join(OUT, "ORACLE_VS_REFERENCE.json")
+        report = json.load(open(path))
+        make_vc(net, OracleSynthesizer(sd), report)
+        with open(path, "w") as f:
+            json.dump(report, f, indent=1)
+        return
     ref_sd = net.state_dict()
     manifest = synthetic.state_dict_manifest(cfg)
     assert list(manifest.keys()) == list(ref_sd.keys()), "manifest order/names differ from the reference"
@@ -183,6 +214,8 @@ def main():
         arrays.update({"stage_" + k: v for k, v in stages.items()})
         arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **{k: to_np(v) for k, v in arrays.items()})
+
+    make_vc(net, oracle, report)
 
     # (vi) full-size C1 / C2: every 97th sample, digest, log-mel summary
     for name, batch in (("c1", synthetic.config_c1()), ("c2", synthetic.config_c2())):

@@ -65,6 +65,10 @@ def _load():
         "vits_frame_prior": (i32, [vp, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp, i64, vp]),
         "vits_flow_workspace_bytes": (i64, [vp, i32, i32]),
         "vits_flow_reverse": (i32, [vp, vp, vp, vp, i32, i32, vp, i64, vp]),
+        "vits_flow_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, i64, vp]),
+        "vits_posterior_channels": (i32, [vp]),
+        "vits_posterior_workspace_bytes": (i64, [vp, i32, i32]),
+        "vits_posterior_encoder": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
         "vits_generator_workspace_bytes": (i64, [vp, i32, i32]),
         "vits_generator": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp]),
         "vits_profile_enable": (None, [i32]),

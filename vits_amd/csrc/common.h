@@ -110,7 +110,7 @@ hipError_t launch_pitch_math(const float* in, bool in_is_hz, float scale, float*
 hipError_t launch_energy_math(const float* in, bool in_is_raw, float scale, float* norm, float* energy, int n,
                               hipStream_t s);
 hipError_t launch_sample(const float* stats, const float* noise, float noise_scale, float* z_p, float* z, int B, int C,
-                         int L, hipStream_t s);
+                         int L, hipStream_t s, const int* lengths = nullptr);
 // length regulator
 hipError_t launch_lr_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, hipStream_t s);
 hipError_t launch_lr_gather(const float* x, const int* cum, const int* totals, float* out, int B, int C, int P, int T,

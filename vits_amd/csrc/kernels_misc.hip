@@ -599,26 +599,29 @@ hipError_t launch_energy_math(const float* in, bool in_is_raw, float scale, floa
 }
 
 // z_p = m_p + noise * exp(logs_p) * noise_scale, with stats = [B, 2C, L] holding m_p then logs_p; z gets a copy.
+// lengths != nullptr: positions t >= lengths[b] are zeroed (posterior encoder, reference models.py:249).
 __global__ void sample_kernel(const float* __restrict__ stats, const float* __restrict__ noise, float noise_scale,
-                              float* __restrict__ z_p, float* __restrict__ z, int B, int C, int L) {
+                              float* __restrict__ z_p, float* __restrict__ z, int B, int C, int L,
+                              const int* __restrict__ lengths) {
   const long long n = (long long)B * C * L;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
     const long long cl = idx % ((long long)C * L);
     const long long b = idx / ((long long)C * L);
     const float m = stats[b * 2 * C * L + cl];
     const float ls = stats[b * 2 * C * L + (long long)C * L + cl];
-    const float v = m + noise[idx] * expf(ls) * noise_scale;
+    float v = m + noise[idx] * expf(ls) * noise_scale;
+    if (lengths && (int)(cl % L) >= lengths[b]) v = 0.f;
     z_p[idx] = v;
     z[idx] = v;
   }
 }
 
 hipError_t launch_sample(const float* stats, const float* noise, float noise_scale, float* z_p, float* z, int B, int C,
-                         int L, hipStream_t s) {
+                         int L, hipStream_t s, const int* lengths) {
   const long long n = (long long)B * C * L;
   if (n <= 0) return hipErrorInvalidValue;
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  hipLaunchKernelGGL(sample_kernel, dim3(blocks), dim3(256), 0, s, stats, noise, noise_scale, z_p, z, B, C, L);
+  hipLaunchKernelGGL(sample_kernel, dim3(blocks), dim3(256), 0, s, stats, noise, noise_scale, z_p, z, B, C, L, lengths);
   return hipGetLastError();
 }
 

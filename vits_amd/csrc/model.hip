@@ -68,7 +68,12 @@ struct vits_model {
   std::vector<ConvDesc> ups;
   std::vector<ResBlock> rbs;
   const float* conv_post_w = nullptr;
-  int cond_rows = 0, off_dp = 0, off_pitch = 0, off_energy = 0, off_dec = 0, off_flow = 0;
+  int cond_rows = 0, off_dp = 0, off_pitch = 0, off_energy = 0, off_dec = 0, off_flow = 0, off_encq = 0;
+  // posterior encoder (voice conversion only; present when the checkpoint's enc_q.* convs were registered)
+  bool has_encq = false;
+  int encq_cin = 0;                  // spectrogram channels rounded up to a multiple of 16
+  ConvDesc encq_pre, encq_proj;
+  FlowLayer encq;                    // its WN: in / res / skip lists (pre and post unused)
   int total_up = 1;
   // side streams + events so that the generator's independent ResBlock chains can overlap (one chain's
   // memory-bound phases run under another chain's MFMA phases); created at finalize on the then-current device
@@ -303,6 +308,24 @@ int vits_model_finalize(vits_model* m) {
   const int ch0 = c.upsample_initial_channel;
   m->off_dp = 0; m->off_pitch = C; m->off_energy = 2 * C; m->off_dec = 3 * C; m->off_flow = 3 * C + ch0;
   m->cond_rows = m->off_flow + c.n_flows * 2 * C * c.flow_layers;
+  // optional posterior encoder: its layer count and input width come from what was registered
+  m->has_encq = m->convs.count("enc_q.pre") > 0;
+  m->encq = FlowLayer();
+  if (m->has_encq) {
+    int nlq = 0;
+    while (m->convs.count("enc_q.in." + std::to_string(nlq))) ++nlq;
+    if (nlq == 0) return fail(VITS_ERR_MISSING, "model is missing enc_q.in.0 (conv not set)");
+    m->encq_cin = m->convs["enc_q.pre"].Cin;
+    m->encq_pre = need_conv(m, "enc_q.pre", m->encq_cin, C, 1, MODE_PLAIN, miss);
+    m->encq_proj = need_conv(m, "enc_q.proj", C, 2 * c.inter_channels, 1, MODE_PLAIN, miss);
+    for (int l = 0; l < nlq; ++l) {
+      m->encq.in.push_back(need_conv(m, "enc_q.in." + std::to_string(l), C, 2 * C, c.flow_kernel, MODE_GATE, miss));
+      if (l + 1 < nlq) m->encq.res.push_back(need_conv(m, "enc_q.res." + std::to_string(l), C, C, 1, MODE_PLAIN, miss));
+      m->encq.skip.push_back(need_conv(m, "enc_q.skip." + std::to_string(l), C, C, 1, MODE_PLAIN, miss));
+    }
+    m->off_encq = m->cond_rows;
+    m->cond_rows += 2 * C * nlq;
+  }
   m->cond_w = need_plain(m, "cond.w", (int64_t)m->cond_rows * G, miss);
   m->cond_b = need_plain(m, "cond.b", m->cond_rows, miss);
   const int nlayers[3] = {c.n_layers, c.pitch_layers, c.n_layers};
@@ -620,10 +643,28 @@ int64_t vits_flow_workspace_bytes(const vits_model* m, int B, int T) {
   return 3 * pad256((int64_t)B * m->cfg.hidden_channels * T);
 }
 
-int vits_flow_reverse(const vits_model* m, float* z, const int* lengths, const float* cond, int B, int T, void* ws,
-                      int64_t ws_bytes, void* stream) {
-  CHECK_MODEL(m);
-  hipStream_t s = (hipStream_t)stream;
+// modules.WN.forward (reference modules.py:144-172) on h (updated in place), result in `skip`: per layer the gated conv
+// with its slice of the conditioning, then the 1x1 res / skip convs (the reference's single res_skip conv, split).
+static int run_wn(const FlowLayer& wn, float* h, float* acts, float* skip, const float* cf, int cr, int C, int B, int T,
+                  const int* lengths, hipStream_t s) {
+  const int NL = (int)wn.in.size();
+  for (int l = 0; l < NL; ++l) {
+    TRY(conv_simple(wn.in[l], h, acts, B, T, lengths, 0, s, nullptr, cf + (long long)l * 2 * C, cr));
+    if (l + 1 < NL) {
+      TRY(conv_simple(wn.res[l], acts, h, B, T, lengths, F_RES | F_MASK_POST, s, h));
+      TRY(conv_simple(wn.skip[l], acts, skip, B, T, lengths, l ? F_ACCUM : 0, s));
+    } else {
+      TRY(conv_simple(wn.skip[l], acts, skip, B, T, lengths, (l ? F_ACCUM : 0) | F_MASK_POST, s));
+    }
+  }
+  return VITS_OK;
+}
+
+// One pass of the coupling block over z, in place.  reverse: layers nf-1 .. 0, x1 = (x1 - m) * mask (synthesis,
+// reference models.py:213-216, modules.py:336-339); forward: layers 0 .. nf-1, x1 = m + x1 * mask (voice conversion,
+// models.py:209-212, modules.py:331-335).
+static int run_flow(const vits_model* m, float* z, const int* lengths, const float* cond, int B, int T, void* ws,
+                    int64_t ws_bytes, hipStream_t s, bool reverse) {
   const int C = m->cfg.hidden_channels, IC = m->cfg.inter_channels, half = IC / 2, NL = m->cfg.flow_layers;
   const int cr = m->cond_rows, nf = m->cfg.n_flows;
   Arena ar(ws, ws_bytes);
@@ -631,10 +672,12 @@ int vits_flow_reverse(const vits_model* m, float* z, const int* lengths, const f
   float* acts = ar.take((int64_t)B * C * T);
   float* skip = ar.take((int64_t)B * C * T);
   if (!h || !acts || !skip) return fail(VITS_ERR_WORKSPACE, "flow: workspace too small");
-  for (int f = nf - 1; f >= 0; --f) {
-    // The reference flips all channels before every coupling layer (models.py:214-215, modules.py:266-273).  Here z
+  for (int step = 0; step < nf; ++step) {
+    const int f = reverse ? nf - 1 - step : step;
+    // The reference flips all channels around every coupling layer (models.py:206-216, modules.py:266-273).  Here z
     // stays in place: after an odd number of flips the layer reads the upper half as x0 and rewrites the lower half,
     // and the channel reversal inside each half is folded into pre's input order and post's output order at load.
+    // Layer f has seen nf - f flips on the way back and f on the way forward: the same parity, because nf is even.
     const bool flipped = (nf - f) & 1;
     float* x0 = z + (flipped ? (long long)half * T : 0);
     float* x1 = z + (flipped ? 0 : (long long)half * T);
@@ -643,23 +686,53 @@ int vits_flow_reverse(const vits_model* m, float* z, const int* lengths, const f
       ConvArgs a = base_args(x0, (long long)IC * T, T, h, (long long)C * T, T, B, T, lengths, F_MASK_PRE);
       HIP_TRY(launch_conv(fl.pre, a, s));
     }
-    const float* cf = cond + m->off_flow + (long long)f * 2 * C * NL;
-    for (int l = 0; l < NL; ++l) {
-      TRY(conv_simple(fl.in[l], h, acts, B, T, lengths, 0, s, nullptr, cf + (long long)l * 2 * C, cr));
-      if (l + 1 < NL) {
-        TRY(conv_simple(fl.res[l], acts, h, B, T, lengths, F_RES | F_MASK_POST, s, h));
-        TRY(conv_simple(fl.skip[l], acts, skip, B, T, lengths, l ? F_ACCUM : 0, s));
-      } else {
-        TRY(conv_simple(fl.skip[l], acts, skip, B, T, lengths, (l ? F_ACCUM : 0) | F_MASK_POST, s));
-      }
-    }
+    TRY(run_wn(fl, h, acts, skip, cond + m->off_flow + (long long)f * 2 * C * NL, cr, C, B, T, lengths, s));
     {
       ConvArgs a = base_args(skip, (long long)C * T, T, x1, (long long)IC * T, T, B, T, lengths,
-                             F_MASK_PRE | F_RES_SUB | F_MASK_POST);
+                             F_MASK_PRE | (reverse ? F_RES_SUB : F_RES) | F_MASK_POST);
       a.res = x1; a.res_bs = (long long)IC * T; a.res_cs = T;
       HIP_TRY(launch_conv(fl.post, a, s));
     }
   }
+  return VITS_OK;
+}
+
+int vits_flow_reverse(const vits_model* m, float* z, const int* lengths, const float* cond, int B, int T, void* ws,
+                      int64_t ws_bytes, void* stream) {
+  CHECK_MODEL(m);
+  return run_flow(m, z, lengths, cond, B, T, ws, ws_bytes, (hipStream_t)stream, true);
+}
+
+int vits_flow_forward(const vits_model* m, float* z, const int* lengths, const float* cond, int B, int T, void* ws,
+                      int64_t ws_bytes, void* stream) {
+  CHECK_MODEL(m);
+  return run_flow(m, z, lengths, cond, B, T, ws, ws_bytes, (hipStream_t)stream, false);
+}
+
+int vits_posterior_channels(const vits_model* m) { return m && m->finalized && m->has_encq ? m->encq_cin : -1; }
+
+int64_t vits_posterior_workspace_bytes(const vits_model* m, int B, int T) {
+  if (!m) return -1;
+  return 3 * pad256((int64_t)B * m->cfg.hidden_channels * T);
+}
+
+int vits_posterior_encoder(const vits_model* m, const float* spec, const int* lengths, const float* cond, int B, int T,
+                           const float* noise, float* stats, float* z, void* ws, int64_t ws_bytes, void* stream) {
+  CHECK_MODEL(m);
+  if (!m->has_encq) return fail(VITS_ERR_MISSING, "posterior encoder: the model was loaded without enc_q.* weights");
+  if (!spec || !lengths || !cond || !noise || !stats || !z) return fail(VITS_ERR_INVALID, "posterior encoder: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = m->cfg.hidden_channels, IC = m->cfg.inter_channels;
+  Arena ar(ws, ws_bytes);
+  float* h = ar.take((int64_t)B * C * T);
+  float* acts = ar.take((int64_t)B * C * T);
+  float* skip = ar.take((int64_t)B * C * T);
+  if (!h || !acts || !skip) return fail(VITS_ERR_WORKSPACE, "posterior encoder: workspace too small");
+  // x = pre(spec) * mask; x = WN(x, mask, g); stats = proj(x) * mask; z = (m + eps * exp(logs)) * mask
+  TRY(conv_simple(m->encq_pre, spec, h, B, T, lengths, F_MASK_PRE, s));
+  TRY(run_wn(m->encq, h, acts, skip, cond + m->off_encq, m->cond_rows, C, B, T, lengths, s));
+  TRY(conv_simple(m->encq_proj, skip, stats, B, T, lengths, F_MASK_PRE, s));
+  HIP_TRY(launch_sample(stats, noise, 1.f, z, z, B, IC, T, s, lengths));
   return VITS_OK;
 }
 

@@ -22,7 +22,8 @@ _DUR_DTYPES = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.float64: 
 
 
 class SynthesizerTrn:
-    """Inference-only synthesizer (the training nets of the reference, enc_q and the discriminators, are not built)."""
+    """Inference-only synthesizer: infer, infer_stream and voice_conversion (the posterior encoder is built when the
+    checkpoint holds its weights; the reference's training forward and discriminators are not)."""
 
     def __init__(self, n_vocab, spec_channels, hop_length, sampling_rate, segment_size, inter_channels,
                  hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, resblock,
@@ -223,6 +224,68 @@ class SynthesizerTrn:
         fe = self._frontend(phonemes, phonemes_lengths, sid, noise_scale, max_len, energy_control, pitch_control,
                             duration_control, noise, None)
         return InferStream(self, fe, int(chunk_frames))
+
+    @torch.no_grad()
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, noise=None):
+        """reference models.py:769-777: posterior encoder on the linear spectrogram y [B, spec_channels, T] with the
+        source speaker, flow forward (source), flow reverse (target), generator (target).  Returns
+        (o_hat [B, 1, T * hop], y_mask float [B, 1, T], (z, z_p, z_hat)).  Needs the checkpoint's enc_q.* weights.
+        Extra keyword ``noise`` ([B, inter_channels, T]) replaces the torch.randn_like draw at models.py:249."""
+        if not self._ready:
+            raise RuntimeError("no weights loaded: call load_state_dict / utils.load_checkpoint first")
+        lib, h, dev = N.lib, self._handle, self.device
+        pc = lib.vits_posterior_channels(h)
+        if pc < 0:
+            raise RuntimeError("voice_conversion needs the posterior encoder: load a checkpoint that holds enc_q.*")
+        if y.dim() != 3 or y.shape[1] != self.cfg.spec_channels:
+            raise ValueError(f"y must be [B, {self.cfg.spec_channels}, T]")
+        B, S, T = y.shape
+        if T > 2048:
+            raise ValueError("at most 2048 frames per utterance")
+        IC = self.cfg.inter_channels
+        f32 = dict(dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            spec = torch.zeros(B, pc, T, **f32)                  # channel count rounded up to a multiple of 16
+            spec[:, :S] = y.to(dev, torch.float32)
+            lens = y_lengths.to(dev, torch.int32).contiguous()
+            if lens.numel() != B:
+                raise ValueError("y_lengths must have one entry per batch row")
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            conds = []
+            for sid in (sid_src, sid_tgt):
+                sids = sid.to(dev, torch.int64).contiguous().reshape(-1)
+                if sids.numel() != B:
+                    raise ValueError("sid_src and sid_tgt must have one entry per batch row")
+                c = torch.empty(B, lib.vits_cond_rows(h), **f32)
+                N.check(lib.vits_speaker_cond(h, sids.data_ptr(), B, c.data_ptr(), err.data_ptr(), stream), "speaker_cond")
+                conds.append(c)
+            if noise is None:
+                noise_t = torch.randn(B, IC, T, **f32)
+            else:
+                noise_t = noise.to(dev, torch.float32).contiguous()
+                if tuple(noise_t.shape) != (B, IC, T):
+                    raise ValueError(f"noise must be [{B}, {IC}, {T}]")
+            ws = self._workspace(max(lib.vits_posterior_workspace_bytes(h, B, T), lib.vits_flow_workspace_bytes(h, B, T),
+                                     lib.vits_generator_workspace_bytes(h, B, T)))
+            stats = torch.empty(B, 2 * IC, T, **f32)
+            z = torch.empty(B, IC, T, **f32)
+            N.check(lib.vits_posterior_encoder(h, spec.data_ptr(), lens.data_ptr(), conds[0].data_ptr(), B, T,
+                                               noise_t.data_ptr(), stats.data_ptr(), z.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), stream), "posterior_encoder")
+            z_p = z.clone()
+            N.check(lib.vits_flow_forward(h, z_p.data_ptr(), lens.data_ptr(), conds[0].data_ptr(), B, T, ws.data_ptr(),
+                                          ws.numel(), stream), "flow_forward")
+            z_hat = z_p.clone()
+            N.check(lib.vits_flow_reverse(h, z_hat.data_ptr(), lens.data_ptr(), conds[1].data_ptr(), B, T, ws.data_ptr(),
+                                          ws.numel(), stream), "flow_reverse")
+            o = torch.empty(B, 1, T * self.total_upsample, **f32)
+            N.check(lib.vits_generator(h, z_hat.data_ptr(), lens.data_ptr(), conds[1].data_ptr(), B, T, T, o.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), stream), "generator")
+            if int(err.cpu()) & 2:
+                raise IndexError("speaker id out of range")
+            y_mask = (torch.arange(T, device=dev)[None, :] < lens[:, None]).unsqueeze(1).to(torch.float32)
+        return o, y_mask, (z, z_p, z_hat)
 
     def _frontend(self, phonemes, phonemes_lengths, sid, noise_scale, max_len, energy_control, pitch_control,
                   duration_control, noise, stages):

@@ -259,6 +259,8 @@ def synthetic_state_dict(cfg: ModelConfig = ModelConfig(), salt: int = 0,
             t = _u(name, shape, 0.26 / math.sqrt(fan_in) * _SQ3, salt)    # pre-tanh std ~0.2: no saturation
         elif name == "project.proj.weight":
             t = _u(name, shape, 0.4 / math.sqrt(fan_in) * _SQ3, salt)     # logs_p std ~0.4
+        elif name == "enc_q.proj.weight":
+            t = _u(name, shape, 0.15 / math.sqrt(fan_in) * _SQ3, salt)    # logs_q std ~0.3: a posterior of unit scale
         elif name.startswith("flow.") and ".post." in name and leaf == "weight":
             t = _u(name, shape, 0.05 * _SQ3, salt)
         elif ".attn_layers." in name and leaf == "weight":
@@ -360,6 +362,18 @@ def config_c3(batch: int = 64) -> SynthBatch:
 def config_c5() -> SynthBatch:
     """C1 with per-phoneme F0 / energy / duration overrides."""
     return make_batch(0, [50], [258], with_controls=True)
+
+
+def make_spectrogram(seed: int, frame_counts, channels: int = 1025):
+    """Synthetic linear-magnitude spectrograms for the voice-conversion path: non-negative, spectral tilt towards
+    low bins, zero beyond each row's length.  Returns (y [B, channels, T] float32, lengths [B] int64)."""
+    gen = torch.Generator().manual_seed(int(seed))
+    B, T = len(frame_counts), int(max(frame_counts))
+    tilt = torch.exp(-torch.arange(channels, dtype=torch.float32) / 300.0)[None, :, None]
+    y = torch.randn(B, channels, T, generator=gen).abs() * 3.0 * tilt
+    lengths = torch.tensor(list(frame_counts), dtype=torch.int64)
+    y = y * (torch.arange(T)[None, None, :] < lengths[:, None, None])
+    return y, lengths
 
 
 def corpus_c4(n_utts: int = 10000, seed: int = 4, max_batch: int = 64):

@@ -12,6 +12,7 @@ import torch
 
 from . import _native as N
 
+# enc_q.* is read by voice_conversion only: prepared when present, never required
 UNUSED_PREFIXES = ("enc_q.", "enc_p.proj.", "frame_prior_net.emb.", "energy_predictor.predictor.proj.")
 
 
@@ -212,6 +213,26 @@ def prepare(sd: Dict[str, torch.Tensor], cfg, precision: int = N.PREC_F32) -> Pr
                 pw.add_conv(f"{o}.skip.{l}", w_rs, b_rs)
         cw.append(folded(sd, p + ".enc.cond_layer")[:, :, 0])
         cb.append(bias(p + ".enc.cond_layer"))
+    # posterior encoder (reference models.py:221-250; voice conversion only): same WN as a flow layer with
+    # cfg.enc_q_layers layers; the spectrogram channels of `pre` are zero-padded to a multiple of 16
+    if "enc_q.pre.weight" in sd:
+        w_pre = folded(sd, "enc_q.pre")
+        pad = -w_pre.shape[1] % 16
+        pw.add_conv("enc_q.pre", torch.nn.functional.pad(w_pre, (0, 0, 0, pad)), bias("enc_q.pre"))
+        pw.add_conv("enc_q.proj", folded(sd, "enc_q.proj"), bias("enc_q.proj"))
+        nlq = cfg.enc_q_layers
+        for l in range(nlq):
+            base = f"enc_q.enc.in_layers.{l}"
+            pw.add_conv(f"enc_q.in.{l}", folded(sd, base), bias(base), mode=N.MODE_GATE)
+            base = f"enc_q.enc.res_skip_layers.{l}"
+            w_rs, b_rs = folded(sd, base), bias(base)
+            if l + 1 < nlq:
+                pw.add_conv(f"enc_q.res.{l}", w_rs[:C], b_rs[:C])
+                pw.add_conv(f"enc_q.skip.{l}", w_rs[C:], b_rs[C:])
+            else:
+                pw.add_conv(f"enc_q.skip.{l}", w_rs, b_rs)
+        cw.append(folded(sd, "enc_q.enc.cond_layer")[:, :, 0])
+        cb.append(bias("enc_q.enc.cond_layer"))
     pw.add_plain("cond.w", torch.cat(cw, 0))
     pw.add_plain("cond.b", torch.cat(cb, 0))
     # generator (reference models.py:257-303, modules.py:183-225)
