@@ -240,7 +240,8 @@ def main():
         # (64 / 32 channels) sit under the HBM roof, the fp32-grade modes under the MFMA roof
         if dom["flops"] / dom["bytes"] < peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
             roof = dict(bound="hbm", kernel=dom["name"], achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
-                        frac=round(gbps / PEAK_HBM_GBPS, 4), tflops=round(achieved, 3))
+                        frac=round(gbps / PEAK_HBM_GBPS, 4), tflops=round(achieved, 3), mfma_peak_tflops=round(peak, 1),
+                        mfma_frac=round(achieved / peak, 4))
         else:
             roof = dict(bound="mfma", kernel=dom["name"], achieved=round(achieved, 3), peak=round(peak, 1),
                         unit="TFLOP/s", frac=round(achieved / peak, 4), algorithmic_gbps=round(gbps, 1))
