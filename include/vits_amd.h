@@ -154,7 +154,12 @@ int vits_profile_read(int index, char* name, int name_len, double* flops, double
  * and output element once in fp32, residual / accumulated-output reads where the epilogue has them, packed weights. */
 int vits_profile_read_bytes(int index, double* bytes);
 
-/* ---- single operators, exposed for unit parity tests ---- */
+/* ---- single operators, exposed for unit parity tests ----
+ * vits_op_conv1d flags (OR of): 1 leaky-relu(in_slope) on the input, 2 input mask, 4 relu, 8 mask before residual,
+ * 16 += res, 32 res - result, 64 += out, 128 mask last, 256 write the result in the staged operand format of the next
+ * conv (leaky-relu(in_slope) applied, converted; plain convs in precision 2 / 3 only), 512 the input is in that format.
+ * Staged format, per batch row: 16-byte units of eight channels of one time step, precision 2: bf16 [C/8][L][8];
+ * precision 3: fp16 [C/8][L][2 planes h, l][8]. */
 int vits_op_conv1d(const void* packed_w, const float* bias_rows, int cin, int rows, int taps, int dilation, int mode,
                    int precision, const float* x, int B, int L, const int* lengths, const float* cbias,
                    const float* in_cbias, const float* res, float* out, int flags, float in_scale, float in_slope,

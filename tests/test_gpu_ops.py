@@ -146,6 +146,51 @@ def test_conv_transpose(N, prec, u, k, cin, cout, L):
     assert (got - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("pname", ["bf16", "f16x2"])
+@pytest.mark.parametrize("C,k,dil,L,B", [(64, 7, 3, 3000, 2), (128, 3, 1, 700, 3), (32, 11, 5, 1500, 2), (256, 3, 1, 90, 2)])
+def test_conv_staged_pair(N, pname, C, k, dil, L, B):
+    """A ResBlock pair with the tensor between the two convs in the second conv's staged operand format: the first
+    conv writes leaky-relu(result) converted (bf16: [C/8][L][8]; f16x2: [C/8][L][h, l][8] fp16), the second copies it
+    into LDS as is.  The values are those the unstaged pair converts at staging, so the final result is bit-identical;
+    the staged bytes are decoded and checked too."""
+    from vits_amd import weights
+    p = PREC[pname]
+    g = torch.Generator().manual_seed(C + k + L)
+    w1 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    w2 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    b1, b2 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    x = torch.randn(B, C, L, generator=g)
+    pk1, pk2 = dev(weights.pack_rows(w1, p)), dev(weights.pack_rows(w2, p))
+    xd, b1d, b2d = dev(x), dev(b1), dev(b2)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def conv(pk, bias, src, dst, dilation, flags, res=None):
+        N.check(N.lib.vits_op_conv1d(pk.data_ptr(), bias.data_ptr(), C, C, k, dilation, 0, p, src.data_ptr(), B, L, 0, 0,
+                                     0, N.ptr(res), dst.data_ptr(), flags, 1.0, 0.1, stream), "op_conv1d")
+
+    t_plain = torch.empty(B, C, L, device="cuda")
+    conv(pk1, b1d, xd, t_plain, dil, N.F_IN_LRELU)
+    out_plain = torch.empty(B, C, L, device="cuda")
+    conv(pk2, b2d, t_plain, out_plain, 1, N.F_IN_LRELU | N.F_RES, res=xd)
+    staged = torch.full((B, C, L), float("nan"), device="cuda")           # an fp32-sized buffer is always enough
+    conv(pk1, b1d, xd, staged, dil, N.F_IN_LRELU | N.F_OUT_STAGED)
+    out_staged = torch.empty(B, C, L, device="cuda")
+    conv(pk2, b2d, staged, out_staged, 1, N.F_IN_STAGED | N.F_RES, res=xd)
+    torch.cuda.synchronize()
+    assert torch.equal(out_staged, out_plain)
+    act = F.leaky_relu(t_plain, 0.1).cpu()
+    flat = staged.reshape(-1).cpu()                    # batch rows are packed back to back in the staged element size
+    if pname == "bf16":
+        got = flat[:B * C * L // 2].contiguous().view(torch.bfloat16).reshape(B, C // 8, L, 8)
+        assert torch.equal(got.permute(0, 1, 3, 2).reshape(B, C, L).float(), act.to(torch.bfloat16).float())
+    else:
+        got = flat.contiguous().view(torch.float16).reshape(B, C // 8, L, 2, 8)
+        h = got[:, :, :, 0].permute(0, 1, 3, 2).reshape(B, C, L).float()
+        lo = got[:, :, :, 1].permute(0, 1, 3, 2).reshape(B, C, L).float()
+        assert torch.equal(h, act.to(torch.float16).float())
+        assert torch.equal(lo, (act - h).to(torch.float16).float())
+
+
 @pytest.mark.parametrize("C,L,mask", [(192, 50, False), (256, 333, True), (768, 70, False), (192, 1, True)])
 def test_layer_norm(N, C, L, mask):
     g = torch.Generator().manual_seed(C + L)

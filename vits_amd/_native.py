@@ -93,6 +93,7 @@ MODE_PLAIN, MODE_GATE, MODE_UP8, MODE_UP4, MODE_UP2 = 0, 1, 2, 3, 4
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16X2 = 0, 1, 2, 3
 PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16x2": PREC_F16X2}
 F_IN_LRELU, F_IN_MASK, F_RELU, F_MASK_PRE, F_RES, F_RES_SUB, F_ACCUM, F_MASK_POST = (1 << i for i in range(8))
+F_OUT_STAGED, F_IN_STAGED = 1 << 8, 1 << 9
 
 
 def check(rc: int, what: str = "") -> None:

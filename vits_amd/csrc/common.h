@@ -34,6 +34,12 @@ enum ConvFlags : int {
   F_RES_SUB   = 1 << 5,   // result = res - result
   F_ACCUM     = 1 << 6,   // result += out (read-modify-write)
   F_MASK_POST = 1 << 7,   // result *= mask last
+  // Staged activations (MODE_PLAIN, PREC_BF16 / PREC_F16X2 only): a tensor that only the next conv reads is written
+  // by its producer already in that conv's LDS operand format -- leaky-relu(out_slope) applied, converted, eight
+  // channels of one time step per 16-byte unit: bf16 [C/8][L][8], f16x2 [C/8][L][2 planes][8] -- so the consumer
+  // stages it with plain 16-byte copies (no prologue, no conversion).  x_bs / out_bs stay in floats.
+  F_OUT_STAGED = 1 << 8,  // write the result in staged format (bias / conditioning bias only; no residual, mask, accumulate)
+  F_IN_STAGED  = 1 << 9,  // the input is in staged format
 };
 
 constexpr int CI_CHUNK = 16;    // input channels staged per LDS tile
@@ -67,6 +73,7 @@ struct ConvArgs {
   int rs;                                            // LDS row stride in floats
   int flags;
   float in_scale, in_slope;
+  float out_slope;                                   // F_OUT_STAGED: leaky-relu slope the consumer would apply
   int toff0[2], tstep[2];                            // tap k reads x[t + toff0 + k * tstep] (per row class)
 };
 

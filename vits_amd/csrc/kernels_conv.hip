@@ -663,6 +663,65 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, uns
 template <int V>
 struct IntC { static constexpr int value = V; };
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// Epilogue for F_OUT_STAGED (MODE_PLAIN): result + bias (+ conditioning bias) -> leaky-relu(out_slope) -> the consumer's
+// operand format.  A lane holds, per 8-row group g of an m-tile, the four channels 8g + 4*par .. + 3 of its time step:
+// half of a 16-byte unit, so one 8-byte store per group (and per plane).  PLANES = 1: bf16; PLANES = 2: fp16 h / l split.
+template <int WM, int WN, int PLANES>
+__device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x16 (&acc)[WM][WN], const int (&mt)[WM],
+                                                     const bool (&mt_ok)[WM], int wn, int par, int l31, int t0, int b) {
+  const float* cbias_b = a.cbias ? a.cbias + (long long)b * a.cbias_bs : nullptr;
+  uint2* out_b = reinterpret_cast<uint2*>(a.out + (long long)b * a.out_bs);      // 8-byte units
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    if (!mt_ok[i]) continue;
+    const int row0 = mt[i] * 32 + 4 * par;
+    float bz[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bz[r] = a.bias ? a.bias[row0 + (r & 3) + 8 * (r >> 2)] : 0.f;
+    if (cbias_b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bz[r] += cbias_b[row0 + (r & 3) + 8 * (r >> 2)];
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int t = t0 + (wn * WN + j) * 32 + l31;
+      if (t >= a.L) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float e = acc[i][j][4 * g + q] + bz[4 * g + q];
+          e = fmaxf(e, e * a.out_slope);
+          v[q] = e;
+        }
+        const long long unit = (long long)(mt[i] * 4 + g) * a.L + t;         // 16-byte unit of (channel group, t)
+        if constexpr (PLANES == 1) {
+          uint2 o;
+          o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+          o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+          out_b[unit * 2 + par] = o;
+        } else {
+          uint2 oh, ol;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            f32x2 e = {fminf(fmaxf(v[2 * u], -65504.f), 65504.f), fminf(fmaxf(v[2 * u + 1], -65504.f), 65504.f)};
+            const f16x2 h = __builtin_convertvector(e, f16x2);
+            const f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, f32x2), f16x2);
+            (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, h);
+            (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, l);
+          }
+          out_b[(unit * 2 + 0) * 2 + par] = oh;
+          out_b[(unit * 2 + 1) * 2 + par] = ol;
+        }
+      }
+    }
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------------------
 // PREC_BF16 kernel: one bf16 product per multiply-accumulate.  Both operands are rounded to nearest-even bf16 (the
@@ -672,7 +731,7 @@ struct IntC { static constexpr int value = V; };
 // matrix work for the same activation traffic, so the long layers of the generator run at the rate HBM delivers
 // their fp32 inputs, residuals and outputs.
 // ---------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int WGM, int WGN, int MODE>
+template <int WM, int WN, int WGM, int WGN, int MODE, bool STG = false>
 __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(const ConvArgs a) {
   constexpr int BN = 32 * WN * WGN;
   constexpr int NCT = (BN + MAX_HALO + 255) / 256;       // tile columns per thread
@@ -681,6 +740,8 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
   static_assert(WGM * WGN == 4, "four waves per block");
   static_assert(!TWO_CLASS || WM == 2, "two-class transposed convs pair the classes in one wave");
   static_assert(MODE != MODE_GATE || WM == 2, "gate pairs the tanh and sigmoid rows in one wave");
+  static_assert(!STG || MODE == MODE_PLAIN, "staged activations are a plain-conv format");
+  constexpr int NPU = 1;                                  // 16-byte units per (channel group, time step)
 
   extern __shared__ __attribute__((aligned(16))) uint4 xq[];    // [2 halves][ncols] of 8 bf16
   const int tid = threadIdx.x, lane = tid & 63;
@@ -699,8 +760,23 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
   const float* xb = a.x + (long long)b * a.x_bs;
   const int tstart = t0 + a.min_off;
   const int wcols = a.width;
-  float st[NCT][16];
+  float st[STG ? 1 : NCT][16];
+  uint4 sp[STG ? NCT : 1][2 * NPU];                         // staged input: the chunk's units of a column, as stored
+  const uint4* xs = reinterpret_cast<const uint4*>(xb);
   auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+    if constexpr (STG) {
+#pragma unroll
+      for (int q = 0; q < NCT; ++q) {
+        const int col = tid + 256 * q, t = tstart + col;
+        const bool ok = col < wcols && t >= 0 && t < a.L;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int p = 0; p < NPU; ++p)
+            sp[q][hf * NPU + p] = xs[((long long)(chunk * 2 + hf) * a.L + (ok ? t : 0)) * NPU + p];
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
       const int col = tid + 256 * q, t = tstart + col;
@@ -714,6 +790,21 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
     }
   };
   auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
+    if constexpr (STG) {
+#pragma unroll
+      for (int q = 0; q < NCT; ++q) {
+        const int col = tid + 256 * q, t = tstart + col;
+        if (col < wcols) {
+          const bool ok = t >= 0 && t < a.L;
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int p = 0; p < NPU; ++p)
+              xq[(p * 2 + hf) * ncols + col] = ok ? sp[q][hf * NPU + p] : make_uint4(0, 0, 0, 0);
+        }
+      }
+      return;
+    }
     const float* cbp = a.in_cbias ? a.in_cbias + (long long)b * a.in_cbias_bs + chunk * 16 : nullptr;
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
@@ -810,6 +901,12 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
     }
   }
 
+  if constexpr (MODE == MODE_PLAIN) {
+    if (a.flags & F_OUT_STAGED) {
+      conv_epilogue_staged<WM, WN, NPU>(a, acc, mt, mt_ok, wn, par, l31, t0, b);
+      return;
+    }
+  }
   conv_epilogue<WM, WN, MODE, true>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
@@ -821,10 +918,7 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
 // a relative error per product of about 2^-22 instead of 2^-24.  Activations are clamped to the fp16 range
 // (+-65504) at staging.  Weights: [Cin/16][tap][M/32][2 planes][64 lanes][8 fp16]; LDS [2 planes][2 halves][ncols].
 // ---------------------------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-template <int WM, int WN, int WGM, int WGN, int MODE>
+template <int WM, int WN, int WGM, int WGN, int MODE, bool STG = false>
 __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(const ConvArgs a) {
   constexpr int BN = 32 * WN * WGN;
   constexpr int NCT = (BN + MAX_HALO + 255) / 256;       // tile columns per thread
@@ -833,6 +927,8 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(co
   static_assert(WGM * WGN == 4, "four waves per block");
   static_assert(!TWO_CLASS || WM == 2, "two-class transposed convs pair the classes in one wave");
   static_assert(MODE != MODE_GATE || WM == 2, "gate pairs the tanh and sigmoid rows in one wave");
+  static_assert(!STG || MODE == MODE_PLAIN, "staged activations are a plain-conv format");
+  constexpr int NPU = 2;                                  // 16-byte units per (channel group, time step)
 
   extern __shared__ __attribute__((aligned(16))) uint4 xq[];    // [2 planes][2 halves][ncols] of 8 fp16
   const int tid = threadIdx.x, lane = tid & 63;
@@ -851,8 +947,23 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(co
   const float* xb = a.x + (long long)b * a.x_bs;
   const int tstart = t0 + a.min_off;
   const int wcols = a.width;
-  float st[NCT][16];
+  float st[STG ? 1 : NCT][16];
+  uint4 sp[STG ? NCT : 1][2 * NPU];                         // staged input: the chunk's units of a column, as stored
+  const uint4* xs = reinterpret_cast<const uint4*>(xb);
   auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+    if constexpr (STG) {
+#pragma unroll
+      for (int q = 0; q < NCT; ++q) {
+        const int col = tid + 256 * q, t = tstart + col;
+        const bool ok = col < wcols && t >= 0 && t < a.L;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int p = 0; p < NPU; ++p)
+            sp[q][hf * NPU + p] = xs[((long long)(chunk * 2 + hf) * a.L + (ok ? t : 0)) * NPU + p];
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
       const int col = tid + 256 * q, t = tstart + col;
@@ -866,6 +977,21 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(co
     }
   };
   auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
+    if constexpr (STG) {
+#pragma unroll
+      for (int q = 0; q < NCT; ++q) {
+        const int col = tid + 256 * q, t = tstart + col;
+        if (col < wcols) {
+          const bool ok = t >= 0 && t < a.L;
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int p = 0; p < NPU; ++p)
+              xq[(p * 2 + hf) * ncols + col] = ok ? sp[q][hf * NPU + p] : make_uint4(0, 0, 0, 0);
+        }
+      }
+      return;
+    }
     const float* cbp = a.in_cbias ? a.in_cbias + (long long)b * a.in_cbias_bs + chunk * 16 : nullptr;
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
@@ -984,6 +1110,12 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(co
     }
   }
 
+  if constexpr (MODE == MODE_PLAIN) {
+    if (a.flags & F_OUT_STAGED) {
+      conv_epilogue_staged<WM, WN, NPU>(a, acc, mt, mt_ok, wn, par, l31, t0, b);
+      return;
+    }
+  }
   conv_epilogue<WM, WN, MODE, true>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
@@ -1016,7 +1148,9 @@ static hipError_t timed_launch(const char* name, bool gate, const ConvArgs& a, h
     const int reads = ((a.flags & (F_RES | F_RES_SUB)) ? 1 : 0) + ((a.flags & F_ACCUM) ? 1 : 0);
     const double wbytes = strstr(name, "conv_mfma") || strstr(name, "conv_f16x2") ? 4.0
                           : strstr(name, "conv_bf16_kernel") ? 2.0 : 6.0;
-    c.bytes += 4.0 * (double)a.L * a.B * (a.Cin + outs * (1 + reads)) + wbytes * a.M * a.Cin * a.K;
+    const double sb = strstr(name, "conv_bf16_kernel") ? 2.0 : 4.0;           // bytes per staged element
+    const double in_b = (a.flags & F_IN_STAGED) ? sb : 4.0, out_b = (a.flags & F_OUT_STAGED) ? sb : 4.0;
+    c.bytes += (double)a.L * a.B * (in_b * a.Cin + outs * (out_b + 4.0 * reads)) + wbytes * a.M * a.Cin * a.K;
     c.count += 1;
     c.pending.emplace_back(e0, e1);
   }
@@ -1062,6 +1196,15 @@ static hipError_t launch_b1(ConvArgs& a, hipStream_t stream) {
   dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
   const size_t lds = (size_t)2 * a.rs * sizeof(uint4);
   char name[96];
+  if constexpr (MODE == MODE_PLAIN) {
+    if (a.flags & F_IN_STAGED) {
+      snprintf(name, sizeof name, "conv_bf16_kernel<%d,%d,%d,%d,%d,staged>", WM, WN, WGM, WGN, MODE);
+      return timed_launch(name, false, a, stream, [&] {
+        hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, WGM, WGN, MODE, true>), grid, dim3(256), lds, stream, a);
+      });
+    }
+  }
+  if (a.flags & F_IN_STAGED) return hipErrorInvalidValue;
   snprintf(name, sizeof name, "conv_bf16_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
   return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
@@ -1077,6 +1220,15 @@ static hipError_t launch_h2(ConvArgs& a, hipStream_t stream) {
   dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
   const size_t lds = (size_t)4 * a.rs * sizeof(uint4);
   char name[96];
+  if constexpr (MODE == MODE_PLAIN) {
+    if (a.flags & F_IN_STAGED) {
+      snprintf(name, sizeof name, "conv_f16x2_kernel<%d,%d,%d,%d,%d,staged>", WM, WN, WGM, WGN, MODE);
+      return timed_launch(name, false, a, stream, [&] {
+        hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, WGM, WGN, MODE, true>), grid, dim3(256), lds, stream, a);
+      });
+    }
+  }
+  if (a.flags & F_IN_STAGED) return hipErrorInvalidValue;
   snprintf(name, sizeof name, "conv_f16x2_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
   return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
@@ -1391,6 +1543,11 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
     a.tstep[c] = d.tstep[c];
   }
   const int L = a.L, M = d.M, p = d.prec;
+  if ((a.flags & (F_IN_STAGED | F_OUT_STAGED)) && (d.mode != MODE_PLAIN || (p != PREC_BF16 && p != PREC_F16X2)))
+    return hipErrorInvalidValue;
+  if ((a.flags & F_OUT_STAGED) && (a.flags & (F_RELU | F_MASK_PRE | F_RES | F_RES_SUB | F_ACCUM | F_MASK_POST)))
+    return hipErrorInvalidValue;
+  if ((a.flags & (F_IN_STAGED | F_OUT_STAGED)) && (d.Cin % 16 || M % 32)) return hipErrorInvalidValue;
   if (p == PREC_BF16X3 && (d.mode == MODE_PLAIN || d.mode == MODE_GATE)) {
     hipError_t err = hipSuccess;
     ConvArgs ak = a;

@@ -159,10 +159,17 @@ ConvArgs base_args(const float* x, long long x_bs, int x_cs, float* out, long lo
 }
 
 // contiguous [B, Cin, L] -> [B, cout, L*up]
+// floats per batch row of a staged activation tensor with C channels (bf16: 2 bytes per element, f16x2: 4)
+inline long long staged_row_floats(int prec, int C, int L) { return prec == PREC_BF16 ? (long long)C * L / 2 : (long long)C * L; }
+
 int conv_simple(const ConvDesc& d, const float* x, float* out, int B, int L, const int* lengths, int flags,
                 hipStream_t s, const float* res = nullptr, const float* cbias = nullptr, int cbias_bs = 0,
-                const float* in_cbias = nullptr, int in_cbias_bs = 0, float in_scale = 1.f, float in_slope = 1.f) {
+                const float* in_cbias = nullptr, int in_cbias_bs = 0, float in_scale = 1.f, float in_slope = 1.f,
+                float out_slope = 1.f) {
   ConvArgs a = base_args(x, (long long)d.Cin * L, L, out, (long long)d.cout * L * d.up, L * d.up, B, L, lengths, flags);
+  if (flags & F_IN_STAGED) a.x_bs = staged_row_floats(d.prec, d.Cin, L);
+  if (flags & F_OUT_STAGED) a.out_bs = staged_row_floats(d.prec, d.cout, L);
+  a.out_slope = out_slope;
   a.res = res; a.res_bs = (long long)d.cout * L; a.res_cs = L;
   a.cbias = cbias; a.cbias_bs = cbias_bs;
   a.in_cbias = in_cbias; a.in_cbias_bs = in_cbias_bs;
@@ -746,6 +753,15 @@ static int64_t gen_buf_floats(const vits_model* m, int B, int t_dec) {
   return mx * B;
 }
 
+// VITS_GEN_STAGED=0 keeps fp32 tensors between the two convs of a ResBlock pair (measurement knob).
+static bool staged_pairs_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_GEN_STAGED");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec) {
   if (!m) return -1;
   return (2 + 2 * (int64_t)m->cfg.n_resblock_kernels) * pad256(gen_buf_floats(m, B, t_dec));
@@ -793,10 +809,16 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
       const ResBlock& rb = m->rbs[i * nk + j];
       const float* yin = X;
       for (int q = 0; q < nd; ++q) {
-        TRY(conv_simple(rb.c1[q], yin, Tt[j], B, L, nullptr, F_IN_LRELU, sj, nullptr, nullptr, 0, nullptr, 0, 1.f, 0.1f));
+        // The tensor between the two convs of a pair has one reader: in the bf16 / f16x2 modes the first conv writes
+        // it already leaky-relu'd and converted, in the second conv's operand format (same values, no conversion at
+        // staging; half the bytes in bf16 mode).
+        const int p1 = rb.c1[q].prec;
+        const bool staged = staged_pairs_enabled() && p1 == rb.c2[q].prec && (p1 == PREC_BF16 || p1 == PREC_F16X2);
+        TRY(conv_simple(rb.c1[q], yin, Tt[j], B, L, nullptr, F_IN_LRELU | (staged ? F_OUT_STAGED : 0), sj, nullptr, nullptr,
+                        0, nullptr, 0, 1.f, 0.1f, 0.1f));
         const bool last = q + 1 == nd;
         float* dst = last ? XS : Y[j];
-        const int flags = F_IN_LRELU | F_RES | (last && j > 0 ? F_ACCUM : 0);
+        const int flags = (staged ? F_IN_STAGED : F_IN_LRELU) | F_RES | (last && j > 0 ? F_ACCUM : 0);
         if (last && j > 0 && n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
         TRY(conv_simple(rb.c2[q], Tt[j], dst, B, L, nullptr, flags, sj, yin, nullptr, 0, nullptr, 0, 1.f, 0.1f));
         yin = Y[j];
@@ -842,7 +864,7 @@ int vits_op_conv1d(const void* w, const float* bias, int cin, int rows, int taps
   ConvDesc d;
   TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode, precision));
   return conv_simple(d, x, out, B, L, lengths, flags, (hipStream_t)stream, res, cbias, rows, in_cbias, cin, in_scale,
-                     in_slope);
+                     in_slope, in_slope);
 }
 
 int vits_op_layer_norm(const float* x, float* y, const float* gamma, const float* beta, const int* lengths, int B, int C,
