@@ -94,7 +94,7 @@ def cpu_baseline(sample_utts=4, runs=2):
                        f"best of {runs} runs after warm-up; PyTorch CPU oracle (oracle/mvts_oracle.py)"), out, b
 
 
-def run_corpus(net, args, device, rank, world, dist):
+def run_corpus(net, args, device, rank, world, dist, red_dev):
     """BASELINE configs[3]: a synthetic corpus (lognormal lengths, 88..1400 frames) sorted by length, cut into
     batches of <= 64 utterances whose composition does not depend on the rank count, whole batches dealt to ranks
     longest-first; every rank synthesises its own batches with no collective on the data path.  Inputs of all of a
@@ -120,7 +120,7 @@ def run_corpus(net, args, device, rank, world, dist):
     mine_s = time.perf_counter() - t0
     elapsed = mine_s
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)      # reporting only: the slowest rank's wall time
         elapsed = float(t.item())
     if rank == 0:
@@ -164,6 +164,9 @@ def main():
                     help="batch (default): one fixed batch per step (C2; C3 with --batch/--frames/--phonemes); "
                          "c4: the sharded synthetic corpus of BASELINE configs[3]")
     ap.add_argument("--utterances", type=int, default=10000, help="corpus size for --workload c4")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend for the timing barrier and the max-over-ranks reduction (nccl = RCCL; "
+                         "gloo lets several ranks rehearse on one GPU: ranks then share device LOCAL_RANK %% device_count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency section (profiling runs)")
     ap.add_argument("--serial-generator", action="store_true",
@@ -178,13 +181,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
+    red_dev = device if args.backend == "nccl" else torch.device("cpu")      # where the elapsed-time reduction lives
 
     if args.serial_generator:
         os.environ["VITS_GEN_STREAMS"] = "1"
@@ -192,7 +199,7 @@ def main():
     from vits_amd import synthetic
     net = build_model(device, args.precision)
     if args.workload == "c4":
-        run_corpus(net, args, device, rank, world, dist)
+        run_corpus(net, args, device, rank, world, dist, red_dev)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -216,7 +223,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
