@@ -50,6 +50,22 @@ def to_device(batch, device):
                 durations=batch.durations.to(device), noise=batch.noise.to(device))
 
 
+def batch_kwargs(d, noise_scale=0.667):
+    return dict(phonemes=d["phonemes"], phonemes_lengths=d["lengths"], sid=d["sid"], noise_scale=noise_scale,
+                duration_control=d["durations"], noise=d["noise"])
+
+
+def run_steps(net, batches, overlap):
+    """One infer per batch.  overlap: SynthesizerTrn.infer_batches (the front end of batch i+1 runs beside the
+    generator of batch i on a second stream); otherwise plain back-to-back infer calls."""
+    if overlap:
+        for _ in net.infer_batches(batch_kwargs(d) for d in batches):
+            pass
+    else:
+        for d in batches:
+            step(net, d)
+
+
 def step(net, d, noise_scale=0.667):
     return net.infer(d["phonemes"], d["lengths"], sid=d["sid"], noise_scale=noise_scale,
                      duration_control=d["durations"], noise=d["noise"])[0]
@@ -108,14 +124,13 @@ def run_corpus(net, args, device, rank, world, dist, red_dev):
         data.append(to_device(synthetic.make_batch(1000 + i, ps, ts), device))
     # warm-up on the rank's largest batch first (sizes the workspace once), then on its smallest
     order = sorted(range(len(mine)), key=lambda j: -sharding.batch_cost(batches[mine[j]]))
-    for j in ([order[0], order[-1]] if order else []):
-        step(net, data[j])
+    overlap = not args.no_overlap
+    run_steps(net, [data[j] for j in ([order[0], order[-1]] if order else [])], overlap)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for d in data:
-        step(net, d)
+    run_steps(net, data, overlap)
     torch.cuda.synchronize(device)
     mine_s = time.perf_counter() - t0
     elapsed = mine_s
@@ -167,6 +182,9 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend for the timing barrier and the max-over-ranks reduction (nccl = RCCL; "
                          "gloo lets several ranks rehearse on one GPU: ranks then share device LOCAL_RANK %% device_count)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="plain back-to-back infer calls in the timed region (default: infer_batches, which overlaps "
+                         "the front end of the next batch with the generator of the current one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency section (profiling runs)")
     ap.add_argument("--serial-generator", action="store_true",
@@ -214,12 +232,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step(net, d)
+    overlap = not args.no_overlap
+    run_steps(net, [d] * args.warmup, overlap)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(net, d)
+    run_steps(net, [d] * args.steps, overlap)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -320,7 +337,8 @@ def main():
                                    f"({args.frames * 512 / 44100:.1f} s each), fixed durations, fixed noise, "
                                    f"{'bf16 generator convs' if net.precision == 'bf16' else 'fp32'}; "
                                    "one batch per GPU per step",
-                       "batch_per_gpu": args.batch, "frames": args.frames, "parallelism": f"utterance-dp{world}"},
+                       "batch_per_gpu": args.batch, "frames": args.frames, "parallelism": f"utterance-dp{world}",
+                       "front_end_overlap": overlap},
             "whole_path_tflops": round(world * args.steps * flops_step / elapsed / 1e12, 2),
             "rtf_batch1": None if args.no_latency else round(rtf, 5),
             "batch1_latency_ms": None if args.no_latency else round(lat[len(lat) // 2] * 1e3, 3),

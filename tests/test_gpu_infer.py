@@ -206,3 +206,35 @@ def test_infer_stream_max_len_and_single_window(gpu_model):
     assert len(one) == 1 and torch.equal(one[0][1], gpu_model.infer(b.phonemes, b.lengths, **kw)[0])
     with pytest.raises(ValueError):
         gpu_model.infer_stream(b.phonemes, b.lengths, chunk_frames=0, **kw)
+
+
+def test_infer_batches_equals_infer(gpu_model):
+    """Throughput mode (front end of batch i+1 beside the generator of batch i on two streams): same bytes as
+    back-to-back infer calls, for batches of different shapes, predicted and given durations, max_len."""
+    bs = [synthetic.make_batch(31, [20, 14], [150, 117]), synthetic.make_batch(32, [9], [40]),
+          synthetic.make_batch(33, [30, 30, 30], [200, 200, 200]), synthetic.make_batch(34, [12, 5], [1, 1])]
+    kws = []
+    for i, b in enumerate(bs):
+        kw = dict(phonemes=b.phonemes, phonemes_lengths=b.lengths, sid=b.sid, noise_scale=b.noise_scale)
+        if i == 3:
+            kw.update(duration_control=1.2)                       # predicted durations: noise must be drawn inside
+        else:
+            kw.update(duration_control=b.durations, noise=b.noise)
+        if i == 1:
+            kw["max_len"] = 33
+        kws.append(kw)
+    torch.manual_seed(77)
+    ref = []
+    for kw in kws:
+        k = dict(kw)
+        ref.append(gpu_model.infer(k.pop("phonemes"), k.pop("phonemes_lengths"), **k))
+    for _ in range(2):                                            # second pass: streams and workspaces already exist
+        torch.manual_seed(77)
+        got = list(gpu_model.infer_batches(kws))
+        assert len(got) == len(ref)
+        for g, r in zip(got, ref):
+            assert torch.equal(g[0], r[0]) and torch.equal(g[1], r[1]) and torch.equal(g[2][0], r[2][0])
+            assert torch.equal(g[4], r[4])
+    assert list(gpu_model.infer_batches([])) == []
+    with pytest.raises(TypeError):
+        list(gpu_model.infer_batches([dict(kws[0], bogus=1)]))

@@ -208,6 +208,84 @@ class SynthesizerTrn:
         return (o,) + fe["outputs"]
 
     @torch.no_grad()
+    def infer_batches(self, batches):
+        """Throughput mode for a sequence of independent batches: yields infer()'s tuple for each element of
+        `batches` (an iterable of dicts of infer()'s arguments; consumed and uploaded up front), in order, with the
+        same values infer() returns.
+
+        The front end of a batch (text encoder ... flow: many short kernels and one host round trip for the frame
+        count) leaves most of the GPU idle, and the generator of the previous batch does not depend on it, so the two
+        run on two streams with separate workspaces: while batch i's generator saturates the chip, batch i+1's front
+        end fills the gaps.  Results are handed over on the caller's current stream (it waits on the generator's
+        event; no host synchronisation), one batch behind the submission."""
+        dev = self.device
+        if getattr(self, "_s_fe", None) is None or self._s_fe.device != dev:
+            # the front end's kernels are short and few blocks wide: on a high-priority stream they take the slots the
+            # generator's blocks free up instead of queueing behind whole generator launches
+            self._s_fe, self._s_gen = torch.cuda.Stream(dev, priority=int(os.environ.get("VITS_FE_PRIORITY", "-1"))), torch.cuda.Stream(dev)
+            self._ws_gen = None
+        lib, h = N.lib, self._handle
+        caller = torch.cuda.current_stream(dev)
+        # Every host tensor is uploaded before the two streams start: a blocking host-to-device copy issued while they
+        # were in flight was seen to hang on this stack (ROCm 7.2, high-priority stream), so none is issued then.
+        batches = [{k: (v.to(dev) if isinstance(v, torch.Tensor) and not v.is_cuda else v) for k, v in kw.items()}
+                   for kw in batches]
+        start = torch.cuda.Event()
+        start.record(caller)
+        self._s_fe.wait_event(start)                        # inputs prepared on the caller's stream are visible
+        self._s_gen.wait_event(start)
+        pending = None
+        for kw in batches:
+            kw = dict(kw)
+            args = (kw.pop("phonemes"), kw.pop("phonemes_lengths"))
+            with torch.cuda.stream(self._s_fe):
+                fe = self._frontend(*args, kw.pop("sid", None), kw.pop("noise_scale", 1), kw.pop("max_len", None),
+                                    kw.pop("energy_control", None), kw.pop("pitch_control", None),
+                                    kw.pop("duration_control", None), kw.pop("noise", None), None)
+                if kw:
+                    raise TypeError(f"unexpected arguments {sorted(kw)}")
+                fe_done = torch.cuda.Event()
+                fe_done.record(self._s_fe)
+            B, T, t_dec = fe["B"], fe["T"], fe["t_dec"]
+            if pending is not None:
+                # One generator call in flight at a time: the library forks and joins its ResBlock chains with one set
+                # of events per model, which must not be recorded again while the previous call still waits on them.
+                # The front end above has already been enqueued (and run) beside that call, so nothing is lost.
+                pending[2].synchronize()
+            # The front end is complete before its generator is enqueued (host wait, not a cross-stream one: a wait on
+            # the trailing marker of the high-priority stream was seen to deadlock against a blocking copy on the
+            # default stream).  The previous generator is still running or just finished, so the chip stays busy.
+            fe_done.synchronize()
+            with torch.cuda.device(dev), torch.cuda.stream(self._s_gen):
+                need = lib.vits_generator_workspace_bytes(h, B, t_dec)
+                if self._ws_gen is None or self._ws_gen.numel() < need:
+                    self._ws_gen = None
+                    self._ws_gen = torch.empty(int(need), dtype=torch.uint8, device=dev)
+                o = torch.empty(B, 1, t_dec * self.total_upsample, dtype=torch.float32, device=dev)
+                for t in (fe["z"], fe["totals"], fe["cond"]):
+                    t.record_stream(self._s_gen)             # allocated on the front-end stream, read here
+                N.check(lib.vits_generator(h, fe["z"].data_ptr(), fe["totals"].data_ptr(), fe["cond"].data_ptr(), B, T,
+                                           t_dec, o.data_ptr(), self._ws_gen.data_ptr(), self._ws_gen.numel(),
+                                           self._s_gen.cuda_stream), "generator")
+                gen_done = torch.cuda.Event()
+                gen_done.record(self._s_gen)
+            if pending is not None:
+                yield self._hand_over(*pending, caller)
+            pending = (o, fe, gen_done)
+        if pending is not None:
+            yield self._hand_over(*pending, caller)
+
+    @staticmethod
+    def _hand_over(o, fe, gen_done, caller):
+        caller.wait_event(gen_done)
+        o.record_stream(caller)
+        for t in fe["outputs"]:
+            for u in (t if isinstance(t, tuple) else (t,)):
+                if isinstance(u, torch.Tensor) and u.is_cuda:
+                    u.record_stream(caller)
+        return (o,) + fe["outputs"]
+
+    @torch.no_grad()
     def infer_stream(self, phonemes, phonemes_lengths, sid=None, noise_scale=1, max_len=None, energy_control=None,
                      pitch_control=None, duration_control=None, noise=None, chunk_frames: int = 64):
         """Chunked synthesis: everything up to the latent z runs once, then the generator runs on windows of
