@@ -126,6 +126,7 @@ def run_corpus(net, args, device, rank, world, dist, red_dev):
     order = sorted(range(len(mine)), key=lambda j: -sharding.batch_cost(batches[mine[j]]))
     overlap = not args.no_overlap
     run_steps(net, [data[j] for j in ([order[0], order[-1]] if order else [])], overlap)
+    torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -202,7 +203,7 @@ def main():
     device = torch.device("cuda", local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("VITS_BENCH_FORCE_DIST") == "1":      # the latter: rehearse the collectives with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -228,6 +229,7 @@ def main():
     audio_s = batch.audio_seconds
 
     def barrier():
+        torch.cuda.synchronize(device)          # this rank's work is complete before the collective runs
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
