@@ -113,16 +113,24 @@ def collate(rows: Sequence[FilelistRow], spk2id: Dict[str, int]) -> Dict[str, to
 def synthesize_rows(net, rows: Sequence[FilelistRow], spk2id: Dict[str, int], max_batch: int = 64,
                     noise_scale: float = 0.667, use_prosody: bool = True, batches: Optional[Iterable[List[int]]] = None,
                     ) -> Iterator[Tuple[int, torch.Tensor]]:
-    """Synthesise filelist rows in length-sorted batches; yields (row index, waveform [samples]) with the padded tail
+    """Synthesise filelist rows in length-sorted batches (through SynthesizerTrn.infer_batches, so the front end of
+    one batch overlaps the generator of the previous one); yields (row index, waveform [samples]) with the padded tail
     cut off.  use_prosody: pass the rows' durations, F0 and energy as overrides (re-synthesis of the recorded
     prosody); otherwise only the phonemes and the speaker are used and the model predicts the rest."""
     hop = net.total_upsample
-    for idx in (batches if batches is not None else make_batches(rows, max_batch)):
-        b = collate([rows[i] for i in idx], spk2id)
-        kw = dict(sid=b["sid"], noise_scale=noise_scale)
-        if use_prosody:
-            kw.update(duration_control=b["durations"], pitch_control=b["f0"], energy_control=b["energy"])
-        o, x_mask, *_ = net.infer(b["phonemes"], b["lengths"], **kw)
-        n_frames = x_mask.sum(dim=(1, 2)).tolist()
-        for j, i in enumerate(idx):
-            yield i, o[j, 0, :int(n_frames[j]) * hop]
+    todo = list(batches if batches is not None else make_batches(rows, max_batch))
+    group = 16                                   # batches handed to the throughput mode at a time (inputs are uploaded up front)
+    for g0 in range(0, len(todo), group):
+        part = todo[g0:g0 + group]
+
+        def kwargs():
+            for idx in part:
+                b = collate([rows[i] for i in idx], spk2id)
+                kw = dict(phonemes=b["phonemes"], phonemes_lengths=b["lengths"], sid=b["sid"], noise_scale=noise_scale)
+                if use_prosody:
+                    kw.update(duration_control=b["durations"], pitch_control=b["f0"], energy_control=b["energy"])
+                yield kw
+        for idx, (o, x_mask, *_) in zip(part, net.infer_batches(kwargs())):
+            n_frames = x_mask.sum(dim=(1, 2)).tolist()
+            for j, i in enumerate(idx):
+                yield i, o[j, 0, :int(n_frames[j]) * hop]
