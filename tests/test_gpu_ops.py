@@ -146,6 +146,23 @@ def test_conv_transpose(N, prec, u, k, cin, cout, L):
     assert (got - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("pname,bound", [("fp32", 2e-6), ("bf16x3", 2e-6), ("f16x2", 2e-6)])
+def test_conv_split_schemes_over_a_wide_dynamic_range(N, pname, bound):
+    """The operand splits must hold their relative accuracy for small and large values alike (fp16 subnormals carry
+    the low term of small operands): inputs spread log-uniformly over 1e-4 .. 1e2, error measured against fp64 and
+    normalised by sum |w| |x|, the scale a per-product relative error acts on.  2^-22 per product (f16x2) plus fp32
+    accumulation stays below 2e-6 of that scale."""
+    g = torch.Generator().manual_seed(123)
+    C, k, L, B = 64, 7, 4000, 2
+    w = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    x = torch.randn(B, C, L, generator=g) * 10.0 ** (torch.rand(B, C, L, generator=g) * 6 - 4)
+    b = torch.zeros(C)
+    got = gpu_conv(N, w, b, x, prec=PREC[pname]).double()
+    ref = F.conv1d(x.double(), w.double(), padding=3)
+    scale = F.conv1d(x.double().abs(), w.double().abs(), padding=3)
+    assert float(((got - ref).abs() / scale).max()) <= bound
+
+
 @pytest.mark.parametrize("pname", ["bf16", "f16x2"])
 @pytest.mark.parametrize("C,k,dil,L,B", [(64, 7, 3, 3000, 2), (128, 3, 1, 700, 3), (32, 11, 5, 1500, 2), (256, 3, 1, 90, 2)])
 def test_conv_staged_pair(N, pname, C, k, dil, L, B):
