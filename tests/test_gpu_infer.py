@@ -238,3 +238,22 @@ def test_infer_batches_equals_infer(gpu_model):
     assert list(gpu_model.infer_batches([])) == []
     with pytest.raises(TypeError):
         list(gpu_model.infer_batches([dict(kws[0], bogus=1)]))
+
+
+def test_infer_at_the_length_limits(gpu_model, oracle_model):
+    """Longest supported utterance: 2048 frames (the attention kernel keeps a whole score row in registers) from
+    400 phonemes, against the oracle; one frame more is refused with a clear error rather than computed wrongly."""
+    b = synthetic.make_batch(41, [400], [2048])
+    kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
+    o = gpu_model.infer(b.phonemes, b.lengths, **kw)[0]
+    assert o.shape == (1, 1, 2048 * 512)
+    ref = oracle_model.infer(b.phonemes, b.lengths, **kw)[0]
+    assert metrics.max_abs(o, ref) <= WAV_TOL
+    assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= MEL_TOL
+    longer = synthetic.make_batch(42, [400], [2049])
+    with pytest.raises(Exception, match="2048"):
+        gpu_model.infer(longer.phonemes, longer.lengths, sid=longer.sid, noise_scale=0.667,
+                        duration_control=longer.durations, noise=longer.noise)
+    # the model still works after the refused call
+    again = gpu_model.infer(b.phonemes, b.lengths, **kw)[0]
+    assert torch.equal(again, o)
