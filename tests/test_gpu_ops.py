@@ -208,6 +208,42 @@ def test_conv_staged_pair(N, pname, C, k, dil, L, B):
         assert torch.equal(lo, (act - h).to(torch.float16).float())
 
 
+@pytest.mark.parametrize("k,dil,L,B,acc", [(3, 1, 1000, 2, False), (7, 3, 3000, 2, True), (11, 5, 2500, 3, False),
+                                           (11, 1, 224, 1, True), (3, 5, 225, 2, False), (7, 5, 50, 2, False)])
+def test_resblock_pair_fused(N, k, dil, L, B, acc):
+    """The fused 32-channel ResBlock pair (tensor between the convs kept in LDS) against the two separate f16x2 convs:
+    same operands in the same order, so the same bytes -- across tile borders (224-step tiles), at both sequence ends
+    (zero padding of the second conv's input) and with the accumulate form used for the sum of the three chains."""
+    from vits_amd import weights
+    p = PREC["f16x2"]
+    g = torch.Generator().manual_seed(k * 100 + dil + L)
+    C = 32
+    w1 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    w2 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    b1, b2 = dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g))
+    x = dev(torch.randn(B, C, L, generator=g))
+    init = dev(torch.randn(B, C, L, generator=g))
+    pk1, pk2 = dev(weights.pack_rows(w1, p)), dev(weights.pack_rows(w2, p))
+    stream = torch.cuda.current_stream().cuda_stream
+    t = torch.empty(B, C, L, device="cuda")
+    N.check(N.lib.vits_op_conv1d(pk1.data_ptr(), b1.data_ptr(), C, C, k, dil, 0, p, x.data_ptr(), B, L, 0, 0, 0, 0,
+                                 t.data_ptr(), N.F_IN_LRELU, 1.0, 0.1, stream), "conv1")
+    ref = init.clone()
+    N.check(N.lib.vits_op_conv1d(pk2.data_ptr(), b2.data_ptr(), C, C, k, 1, 0, p, t.data_ptr(), B, L, 0, 0, 0,
+                                 x.data_ptr(), ref.data_ptr(), N.F_IN_LRELU | N.F_RES | (N.F_ACCUM if acc else 0), 1.0,
+                                 0.1, stream), "conv2")
+    out = init.clone()
+    N.check(N.lib.vits_op_resblock_pair(pk1.data_ptr(), b1.data_ptr(), pk2.data_ptr(), b2.data_ptr(), C, k, dil,
+                                        x.data_ptr(), out.data_ptr(), B, L, 1 if acc else 0, 0.1, stream), "pair")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    # and against plain fp32 math
+    xc = x.cpu()
+    y = F.conv1d(F.leaky_relu(xc, 0.1), w1, b1.cpu(), padding=(k - 1) // 2 * dil, dilation=dil)
+    y = F.conv1d(F.leaky_relu(y, 0.1), w2, b2.cpu(), padding=(k - 1) // 2) + xc + (init.cpu() if acc else 0)
+    assert (out.cpu() - y).abs().max() < 5e-5
+
+
 @pytest.mark.parametrize("C,L,mask", [(192, 50, False), (256, 333, True), (768, 70, False), (192, 1, True)])
 def test_layer_norm(N, C, L, mask):
     g = torch.Generator().manual_seed(C + L)

@@ -77,6 +77,7 @@ def _load():
         "vits_profile_read": (i32, [i32, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int64)]),
         "vits_op_conv1d": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, f32, f32, vp]),
+        "vits_op_resblock_pair": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, C.c_float, vp]),
         "vits_op_layer_norm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "vits_op_attention": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     }

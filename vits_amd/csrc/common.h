@@ -79,6 +79,18 @@ struct ConvArgs {
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
 
+// One ResBlock pair in one launch (32-channel stage, PREC_F16X2): out = x + c2(lrelu(c1(lrelu(x)))) [+ out], with the
+// tensor between the two convs kept in LDS.  x and out must not overlap (blocks read a halo of x).
+struct PairArgs {
+  const float* x; long long x_bs; int x_cs;
+  float* out; long long out_bs; int out_cs;
+  int B, L;
+  int accumulate;                // out += result (read-modify-write)
+  float slope;                   // leaky-relu slope before both convs
+};
+bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2);
+hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const PairArgs& a, hipStream_t stream);
+
 // Optional per-kernel timing of the conv launches with HIP events on the launch stream (off by default).
 struct ProfRow {
   std::string name;      // kernel instantiation, e.g. conv_mfma_kernel<2,2,1,4,0> = <WM,WN,WGM,WGN,MODE>

@@ -1585,4 +1585,231 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused ResBlock pair for the 32-channel stage (PREC_F16X2): out = x + c2(lrelu(c1(lrelu(x)))) (+ out).
+// The stage is bandwidth-bound, and the unfused pair moves five tensor passes (x in, t out, t in, x in again, out);
+// here a block computes c1 on 256 time steps into LDS (leaky-relu'd, split into fp16 h / l, in c2's operand layout,
+// zero outside the sequence as c2's padding requires) and c2 on the inner 224 of them, so x is read once (plus halo)
+// and only the result is written.  Same accumulation order per output as the two separate kernels: bit-identical.
+//   block = 4 waves side by side in time; c1: wave tile 32 rows x 64 steps; c2: n-tiles 2w, 2w + 1 of the 7 valid ones.
+//   Y column c <-> time t0 - 16 + c;  c2 output column o <-> time t0 + o, reads Y columns o + 16 + k - (K-1)/2.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PAIR_W1 = 256, PAIR_BN = 224, PAIR_YOFF = 16;
+
+__global__ __launch_bounds__(256, 3) void resblock_pair32_kernel(const PairArgs a, const uint4* __restrict__ w1,
+                                                                 const float* __restrict__ b1,
+                                                                 const uint4* __restrict__ w2,
+                                                                 const float* __restrict__ b2, int K, int dil) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int par = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, t0 = blockIdx.x * PAIR_BN;
+  const int h1 = (K - 1) / 2 * dil, h2 = (K - 1) / 2;
+  const int ncols = PAIR_W1 + 2 * h1;                       // x tile: times t0 - 16 - h1 ... , one column per time step
+  uint4* xq = lds;                                          // [2 planes][2 halves][ncols]
+  uint4* yq = lds + 4 * ncols;                              // [2 chunks][2 planes][2 halves][PAIR_W1] (+ slack)
+  const float* xb = a.x + (long long)b * a.x_bs;
+  const int tx0 = t0 - PAIR_YOFF - h1;
+
+  float st[2][16];
+  auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int col = tid + 256 * q, t = tx0 + col;
+      const bool ok = col < ncols && t >= 0 && t < a.L;
+      const float* xc = xb + (long long)chunk * 16 * a.x_cs + (ok ? t : 0);
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci) st[q][ci] = xc[(long long)ci * a.x_cs];
+    }
+  };
+  auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int col = tid + 256 * q, t = tx0 + col;
+      if (col < ncols) {
+        const bool ok = t >= 0 && t < a.L;
+        unsigned ph[8], pl[8];
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+          f32x2 v;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            float e = st[q][2 * c2 + u];
+            e = fmaxf(e, e * a.slope);
+            e = fminf(fmaxf(e, -65504.f), 65504.f);
+            v[u] = ok ? e : 0.f;
+          }
+          const f16x2 h = __builtin_convertvector(v, f16x2);
+          const f16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), f16x2);
+          ph[c2] = __builtin_bit_cast(unsigned, h);
+          pl[c2] = __builtin_bit_cast(unsigned, l);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          xq[(0 * 2 + hf) * ncols + col] = make_uint4(ph[4 * hf], ph[4 * hf + 1], ph[4 * hf + 2], ph[4 * hf + 3]);
+          xq[(1 * 2 + hf) * ncols + col] = make_uint4(pl[4 * hf], pl[4 * hf + 1], pl[4 * hf + 2], pl[4 * hf + 3]);
+        }
+      }
+    }
+  };
+
+  f32x16 acc[2];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  };
+  auto mma = [&](const uint4& af, const uint4 (&bf)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, bf[j]),
+                                                      acc[j], 0, 0, 0);
+  };
+
+  // ---- first conv: Y columns [64 * wave, 64 * wave + 64) ----
+  zero_acc();
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+  {
+    const int colbase = wave * 64 + l31 + par * ncols;
+    for (int chunk = 0; chunk < 2; ++chunk) {
+      if (chunk == 0) load_chunk(1);
+      for (int k = 0; k < K; ++k) {
+        const uint4* wk = w1 + (long long)(chunk * K + k) * 128 + lane;
+        const uint4 Ah = wk[0], Al = wk[64];
+        const int off = colbase + k * dil;
+        uint4 Bh[2], Bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          Bh[j] = xq[off + j * 32];
+          Bl[j] = xq[2 * ncols + off + j * 32];
+        }
+        mma(Ah, Bl);                                       // h * l
+        mma(Ah, Bh);                                       // h * h
+        mma(Al, Bh);                                       // l * h
+      }
+      if (chunk == 0) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+      }
+    }
+  }
+  // ---- Y = split(lrelu(c1 + bias)), zero outside the sequence; 8-byte pieces (four channels of a half) ----
+  {
+    uint2* y2 = reinterpret_cast<uint2*>(yq);
+    float bz[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bz[r] = b1 ? b1[4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = wave * 64 + j * 32 + l31;
+      const int t = t0 - PAIR_YOFF + c;
+      const bool inside = t >= 0 && t < a.L;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 oh, ol;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f32x2 e;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float v = acc[j][4 * g + 2 * u + q] + bz[4 * g + 2 * u + q];
+            v = fmaxf(v, v * a.slope);
+            v = fminf(fmaxf(v, -65504.f), 65504.f);
+            e[q] = inside ? v : 0.f;
+          }
+          const f16x2 h = __builtin_convertvector(e, f16x2);
+          const f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, f32x2), f16x2);
+          (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, h);
+          (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, l);
+        }
+        const int chunk2 = g >> 1, half = g & 1;
+        y2[(((chunk2 * 2 + 0) * 2 + half) * PAIR_W1 + c) * 2 + par] = oh;
+        y2[(((chunk2 * 2 + 1) * 2 + half) * PAIR_W1 + c) * 2 + par] = ol;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- second conv on the inner 224 steps ----
+  zero_acc();
+  {
+    const int obase = wave * 64 + l31 + PAIR_YOFF - h2 + par * PAIR_W1;
+    for (int chunk = 0; chunk < 2; ++chunk)
+      for (int k = 0; k < K; ++k) {
+        const uint4* wk = w2 + (long long)(chunk * K + k) * 128 + lane;
+        const uint4 Ah = wk[0], Al = wk[64];
+        const int off = (chunk * 4) * PAIR_W1 + obase + k;
+        uint4 Bh[2], Bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          Bh[j] = yq[off + j * 32];
+          Bl[j] = yq[2 * PAIR_W1 + off + j * 32];
+        }
+        mma(Ah, Bl);
+        mma(Ah, Bh);
+        mma(Al, Bh);
+      }
+  }
+  // ---- out = c2 + bias + x (+ out); all loads of the tile before its first store ----
+  {
+    float* ob = a.out + (long long)b * a.out_bs;
+    float bz[16], rv[2][16], ov[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bz[r] = b2 ? b2[4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int o = wave * 64 + j * 32 + l31, t = t0 + o;
+      const int tc = t < a.L ? t : a.L - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 4 * par + (r & 3) + 8 * (r >> 2);
+        rv[j][r] = xb[(long long)row * a.x_cs + tc];
+        ov[j][r] = a.accumulate ? ob[(long long)row * a.out_cs + tc] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int o = wave * 64 + j * 32 + l31, t = t0 + o;
+      if (o < PAIR_BN && t < a.L) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 4 * par + (r & 3) + 8 * (r >> 2);
+          float v = acc[j][r] + bz[r];
+          v += rv[j][r];
+          if (a.accumulate) v += ov[j][r];
+          ob[(long long)row * a.out_cs + t] = v;
+        }
+      }
+    }
+  }
+}
+
+bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2) {
+  return c1.prec == PREC_F16X2 && c2.prec == PREC_F16X2 && c1.mode == MODE_PLAIN && c2.mode == MODE_PLAIN &&
+         c1.M == 32 && c1.Cin == 32 && c2.M == 32 && c2.Cin == 32 && c1.K == c2.K && (c1.K & 1) && c2.tstep[0] == 1 &&
+         (c1.K - 1) / 2 * c1.tstep[0] <= 25 && (c2.K - 1) / 2 <= PAIR_YOFF;
+}
+
+hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const PairArgs& a, hipStream_t stream) {
+  if (!pair_fusable(c1, c2) || a.B <= 0 || a.L <= 0 || a.B > 65535) return hipErrorInvalidValue;
+  const int K = c1.K, dil = c1.tstep[0];
+  const int ncols = PAIR_W1 + 2 * ((K - 1) / 2 * dil);
+  const size_t lds = ((size_t)4 * ncols + (size_t)8 * PAIR_W1 + 64) * sizeof(uint4);   // + slack for the invalid n-tile
+  dim3 grid((a.L + PAIR_BN - 1) / PAIR_BN, 1, a.B);
+  ConvArgs ta;
+  memset(&ta, 0, sizeof ta);
+  ta.M = 32; ta.Cin = 32; ta.K = 2 * K; ta.L = a.L; ta.B = a.B;          // timing row: both convs' FLOPs
+  ta.flags = F_RES | (a.accumulate ? F_ACCUM : 0);
+  char name[64];
+  snprintf(name, sizeof name, "resblock_pair32_kernel<k%d>", K);
+  return timed_launch(name, false, ta, stream, [&] {
+    hipLaunchKernelGGL(resblock_pair32_kernel, grid, dim3(256), lds, stream, a, reinterpret_cast<const uint4*>(c1.w), c1.bias,
+                       reinterpret_cast<const uint4*>(c2.w), c2.bias, K, dil);
+  });
+}
+
 }  // namespace vits

@@ -762,6 +762,15 @@ static bool staged_pairs_enabled() {
   return on;
 }
 
+// VITS_GEN_FUSED=0 keeps the 32-channel ResBlock pairs as two launches (measurement knob).
+static bool fused_pairs_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_GEN_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec) {
   if (!m) return -1;
   return (2 + 2 * (int64_t)m->cfg.n_resblock_kernels) * pad256(gen_buf_floats(m, B, t_dec));
@@ -809,6 +818,20 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
       const ResBlock& rb = m->rbs[i * nk + j];
       const float* yin = X;
       for (int q = 0; q < nd; ++q) {
+        if (fused_pairs_enabled() && pair_fusable(rb.c1[q], rb.c2[q])) {
+          // 32-channel stage: the whole pair in one launch, the tensor between the convs never leaves LDS.  Blocks
+          // read a halo of their input, so the pair cannot run in place: Y and T take turns as the chain's carrier.
+          const bool last = q + 1 == nd;
+          float* dst = last ? XS : ((q & 1) ? Tt[j] : Y[j]);
+          if (last && j > 0 && n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
+          PairArgs pa;
+          pa.x = yin; pa.x_bs = (long long)rb.c1[q].Cin * L; pa.x_cs = L;
+          pa.out = dst; pa.out_bs = (long long)rb.c1[q].Cin * L; pa.out_cs = L;
+          pa.B = B; pa.L = L; pa.accumulate = last && j > 0; pa.slope = 0.1f;
+          HIP_TRY(launch_resblock_pair(rb.c1[q], rb.c2[q], pa, sj));
+          yin = dst;
+          continue;
+        }
         // The tensor between the two convs of a pair has one reader: in the bf16 / f16x2 modes the first conv writes
         // it already leaky-relu'd and converted, in the second conv's operand format (same values, no conversion at
         // staging; half the bytes in bf16 mode).
@@ -865,6 +888,22 @@ int vits_op_conv1d(const void* w, const float* bias, int cin, int rows, int taps
   TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode, precision));
   return conv_simple(d, x, out, B, L, lengths, flags, (hipStream_t)stream, res, cbias, rows, in_cbias, cin, in_scale,
                      in_slope, in_slope);
+}
+
+int vits_op_resblock_pair(const void* w1, const float* b1, const void* w2, const float* b2, int channels, int taps,
+                          int dilation, const float* x, float* out, int B, int L, int accumulate, float slope,
+                          void* stream) {
+  ConvDesc c1, c2;
+  TRY(make_desc(c1, w1, b1, channels, channels, taps, dilation, MODE_PLAIN, PREC_F16X2));
+  TRY(make_desc(c2, w2, b2, channels, channels, taps, 1, MODE_PLAIN, PREC_F16X2));
+  if (!pair_fusable(c1, c2)) return fail(VITS_ERR_INVALID, "resblock pair: 32 channels, odd taps, halo <= 25 required");
+  if (x == out) return fail(VITS_ERR_INVALID, "resblock pair: cannot run in place");
+  PairArgs pa;
+  pa.x = x; pa.x_bs = (long long)channels * L; pa.x_cs = L;
+  pa.out = out; pa.out_bs = (long long)channels * L; pa.out_cs = L;
+  pa.B = B; pa.L = L; pa.accumulate = accumulate; pa.slope = slope;
+  HIP_TRY(launch_resblock_pair(c1, c2, pa, (hipStream_t)stream));
+  return VITS_OK;
 }
 
 int vits_op_layer_norm(const float* x, float* y, const float* gamma, const float* beta, const int* lengths, int B, int C,
