@@ -164,9 +164,9 @@ int vits_op_conv1d(const void* packed_w, const float* bias_rows, int cin, int ro
                    int precision, const float* x, int B, int L, const int* lengths, const float* cbias,
                    const float* in_cbias, const float* res, float* out, int flags, float in_scale, float in_slope,
                    void* stream);
-/* One ResBlock1 pair (reference modules.py:206-219, one iteration of its loop) in a single launch for the 32-channel
- * stage: out = x + conv2(lrelu(conv1(lrelu(x)))) (+ out when accumulate), conv1 dilated, conv2 dilation 1, both with
- * `taps` taps and f16x2-packed weights [32][32][taps]; x and out [B, 32, L], not overlapping. */
+/* One ResBlock1 pair (reference modules.py:206-219, one iteration of its loop) in a single launch:
+ * out = x + conv2(lrelu(conv1(lrelu(x)))) (+ out when accumulate), conv1 dilated, conv2 dilation 1, both with `taps`
+ * taps and f16x2-packed weights [C][C][taps]; C = 32 or 64; x and out [B, C, L], not overlapping. */
 int vits_op_resblock_pair(const void* packed_w1, const float* bias1, const void* packed_w2, const float* bias2,
                           int channels, int taps, int dilation, const float* x, float* out, int B, int L,
                           int accumulate, float slope, void* stream);

@@ -208,16 +208,18 @@ def test_conv_staged_pair(N, pname, C, k, dil, L, B):
         assert torch.equal(lo, (act - h).to(torch.float16).float())
 
 
-@pytest.mark.parametrize("k,dil,L,B,acc", [(3, 1, 1000, 2, False), (7, 3, 3000, 2, True), (11, 5, 2500, 3, False),
-                                           (11, 1, 224, 1, True), (3, 5, 225, 2, False), (7, 5, 50, 2, False)])
-def test_resblock_pair_fused(N, k, dil, L, B, acc):
-    """The fused 32-channel ResBlock pair (tensor between the convs kept in LDS) against the two separate f16x2 convs:
-    same operands in the same order, so the same bytes -- across tile borders (224-step tiles), at both sequence ends
+@pytest.mark.parametrize("C,k,dil,L,B,acc", [(32, 3, 1, 1000, 2, False), (32, 7, 3, 3000, 2, True),
+                                             (32, 11, 5, 2500, 3, False), (32, 11, 1, 224, 1, True),
+                                             (32, 3, 5, 225, 2, False), (32, 7, 5, 50, 2, False),
+                                             (64, 3, 1, 1000, 2, True), (64, 7, 5, 97, 3, False), (64, 11, 3, 96, 1, False)])
+def test_resblock_pair_fused(N, C, k, dil, L, B, acc):
+    """The fused ResBlock pair (32 or 64 channels; tensor between the convs kept in LDS) against
+    the two separate f16x2 convs: same operands in the same order, so the same bytes -- across tile borders (224- and
+    96-step tiles), at both sequence ends
     (zero padding of the second conv's input) and with the accumulate form used for the sum of the three chains."""
     from vits_amd import weights
     p = PREC["f16x2"]
     g = torch.Generator().manual_seed(k * 100 + dil + L)
-    C = 32
     w1 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
     w2 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
     b1, b2 = dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g))

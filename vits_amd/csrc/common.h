@@ -88,7 +88,8 @@ struct PairArgs {
   int accumulate;                // out += result (read-modify-write)
   float slope;                   // leaky-relu slope before both convs
 };
-bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2);
+bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2);       // the kernel supports the shape (32 or 64 channels)
+bool pair_profitable(const ConvDesc& c1, const ConvDesc& c2);    // ... and is the faster choice for it
 hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const PairArgs& a, hipStream_t stream);
 
 // Optional per-kernel timing of the conv launches with HIP events on the launch stream (off by default).

@@ -1594,28 +1594,33 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
 //   block = 4 waves side by side in time; c1: wave tile 32 rows x 64 steps; c2: n-tiles 2w, 2w + 1 of the 7 valid ones.
 //   Y column c <-> time t0 - 16 + c;  c2 output column o <-> time t0 + o, reads Y columns o + 16 + k - (K-1)/2.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int PAIR_W1 = 256, PAIR_BN = 224, PAIR_YOFF = 16;
+constexpr int PAIR_YOFF = 16;
 
-__global__ __launch_bounds__(256, 3) void resblock_pair32_kernel(const PairArgs a, const uint4* __restrict__ w1,
-                                                                 const float* __restrict__ b1,
-                                                                 const uint4* __restrict__ w2,
-                                                                 const float* __restrict__ b2, int K, int dil) {
+// MT = channels / 32: MT waves side by side in rows (one 32-row tile each), 4 / MT in time (64 steps each).
+template <int MT>
+__global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a, const uint4* __restrict__ w1,
+                                                               const float* __restrict__ b1,
+                                                               const uint4* __restrict__ w2,
+                                                               const float* __restrict__ b2, int K, int dil) {
+  constexpr int WGN = 4 / MT, W1 = 64 * WGN, BN = W1 - 32, NCH = 2 * MT;
+  constexpr int NCT = (W1 + 50 + 255) / 256;                // x-tile columns per thread
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
   const int par = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.z, t0 = blockIdx.x * PAIR_BN;
+  const int b = blockIdx.z, t0 = blockIdx.x * BN;
   const int h1 = (K - 1) / 2 * dil, h2 = (K - 1) / 2;
-  const int ncols = PAIR_W1 + 2 * h1;                       // x tile: times t0 - 16 - h1 ... , one column per time step
+  const int ncols = W1 + 2 * h1;                            // x tile: times t0 - 16 - h1 ... , one column per time step
   uint4* xq = lds;                                          // [2 planes][2 halves][ncols]
-  uint4* yq = lds + 4 * ncols;                              // [2 chunks][2 planes][2 halves][PAIR_W1] (+ slack)
+  uint4* yq = lds + 4 * ncols;                              // [NCH chunks][2 planes][2 halves][W1] (+ slack)
   const float* xb = a.x + (long long)b * a.x_bs;
   const int tx0 = t0 - PAIR_YOFF - h1;
 
-  float st[2][16];
+  float st[NCT][16];
   auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NCT; ++q) {
       const int col = tid + 256 * q, t = tx0 + col;
       const bool ok = col < ncols && t >= 0 && t < a.L;
       const float* xc = xb + (long long)chunk * 16 * a.x_cs + (ok ? t : 0);
@@ -1625,7 +1630,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair32_kernel(const PairArgs 
   };
   auto store_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NCT; ++q) {
       const int col = tid + 256 * q, t = tx0 + col;
       if (col < ncols) {
         const bool ok = t >= 0 && t < a.L;
@@ -1668,17 +1673,17 @@ __global__ __launch_bounds__(256, 3) void resblock_pair32_kernel(const PairArgs 
                                                       acc[j], 0, 0, 0);
   };
 
-  // ---- first conv: Y columns [64 * wave, 64 * wave + 64) ----
+  // ---- first conv: rows 32 * wm .., Y columns [64 * wn, 64 * wn + 64) ----
   zero_acc();
   load_chunk(0);
   store_chunk();
   __syncthreads();
   {
-    const int colbase = wave * 64 + l31 + par * ncols;
-    for (int chunk = 0; chunk < 2; ++chunk) {
-      if (chunk == 0) load_chunk(1);
+    const int colbase = wn * 64 + l31 + par * ncols;
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+      if (chunk + 1 < NCH) load_chunk(chunk + 1);
       for (int k = 0; k < K; ++k) {
-        const uint4* wk = w1 + (long long)(chunk * K + k) * 128 + lane;
+        const uint4* wk = w1 + ((long long)(chunk * K + k) * MT + wm) * 128 + lane;
         const uint4 Ah = wk[0], Al = wk[64];
         const int off = colbase + k * dil;
         uint4 Bh[2], Bl[2];
@@ -1691,7 +1696,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair32_kernel(const PairArgs 
         mma(Ah, Bh);                                       // h * h
         mma(Al, Bh);                                       // l * h
       }
-      if (chunk == 0) {
+      if (chunk + 1 < NCH) {
         __syncthreads();
         store_chunk();
         __syncthreads();
@@ -1703,10 +1708,10 @@ __global__ __launch_bounds__(256, 3) void resblock_pair32_kernel(const PairArgs 
     uint2* y2 = reinterpret_cast<uint2*>(yq);
     float bz[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bz[r] = b1 ? b1[4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+    for (int r = 0; r < 16; ++r) bz[r] = b1 ? b1[32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int c = wave * 64 + j * 32 + l31;
+      const int c = wn * 64 + j * 32 + l31;
       const int t = t0 - PAIR_YOFF + c;
       const bool inside = t >= 0 && t < a.L;
 #pragma unroll
@@ -1727,27 +1732,27 @@ __global__ __launch_bounds__(256, 3) void resblock_pair32_kernel(const PairArgs 
           (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, h);
           (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, l);
         }
-        const int chunk2 = g >> 1, half = g & 1;
-        y2[(((chunk2 * 2 + 0) * 2 + half) * PAIR_W1 + c) * 2 + par] = oh;
-        y2[(((chunk2 * 2 + 1) * 2 + half) * PAIR_W1 + c) * 2 + par] = ol;
+        const int chunk2 = 2 * wm + (g >> 1), half = g & 1;
+        y2[(((chunk2 * 2 + 0) * 2 + half) * W1 + c) * 2 + par] = oh;
+        y2[(((chunk2 * 2 + 1) * 2 + half) * W1 + c) * 2 + par] = ol;
       }
     }
   }
   __syncthreads();
-  // ---- second conv on the inner 224 steps ----
+  // ---- second conv on the inner BN steps ----
   zero_acc();
   {
-    const int obase = wave * 64 + l31 + PAIR_YOFF - h2 + par * PAIR_W1;
-    for (int chunk = 0; chunk < 2; ++chunk)
+    const int obase = wn * 64 + l31 + PAIR_YOFF - h2 + par * W1;
+    for (int chunk = 0; chunk < NCH; ++chunk)
       for (int k = 0; k < K; ++k) {
-        const uint4* wk = w2 + (long long)(chunk * K + k) * 128 + lane;
+        const uint4* wk = w2 + ((long long)(chunk * K + k) * MT + wm) * 128 + lane;
         const uint4 Ah = wk[0], Al = wk[64];
-        const int off = (chunk * 4) * PAIR_W1 + obase + k;
+        const int off = (chunk * 4) * W1 + obase + k;
         uint4 Bh[2], Bl[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           Bh[j] = yq[off + j * 32];
-          Bl[j] = yq[2 * PAIR_W1 + off + j * 32];
+          Bl[j] = yq[2 * W1 + off + j * 32];
         }
         mma(Ah, Bl);
         mma(Ah, Bh);
@@ -1759,25 +1764,25 @@ __global__ __launch_bounds__(256, 3) void resblock_pair32_kernel(const PairArgs 
     float* ob = a.out + (long long)b * a.out_bs;
     float bz[16], rv[2][16], ov[2][16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bz[r] = b2 ? b2[4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+    for (int r = 0; r < 16; ++r) bz[r] = b2 ? b2[32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int o = wave * 64 + j * 32 + l31, t = t0 + o;
+      const int o = wn * 64 + j * 32 + l31, t = t0 + o;
       const int tc = t < a.L ? t : a.L - 1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = 4 * par + (r & 3) + 8 * (r >> 2);
+        const int row = 32 * wm + 4 * par + (r & 3) + 8 * (r >> 2);
         rv[j][r] = xb[(long long)row * a.x_cs + tc];
         ov[j][r] = a.accumulate ? ob[(long long)row * a.out_cs + tc] : 0.f;
       }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int o = wave * 64 + j * 32 + l31, t = t0 + o;
-      if (o < PAIR_BN && t < a.L) {
+      const int o = wn * 64 + j * 32 + l31, t = t0 + o;
+      if (o < BN && t < a.L) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = 4 * par + (r & 3) + 8 * (r >> 2);
+          const int row = 32 * wm + 4 * par + (r & 3) + 8 * (r >> 2);
           float v = acc[j][r] + bz[r];
           v += rv[j][r];
           if (a.accumulate) v += ov[j][r];
@@ -1788,27 +1793,46 @@ __global__ __launch_bounds__(256, 3) void resblock_pair32_kernel(const PairArgs 
   }
 }
 
+// Where the fused pair is the faster choice (measured at 16 x 3 s): every 32-channel pair (k = 3: 217 against 363 us,
+// k = 7: 312 / 372, k = 11: 401 / 442).  At 64 channels the tile is 96 steps wide (the intermediate has to fit in LDS
+// three blocks to a CU), and the halo re-reads and the wider first conv eat the saved traffic: k = 3 equal, k = 7 and 11
+// slower.  VITS_PAIR64=3,7 (a list of tap counts) turns it on there for measurements.
+static bool pair64_taps(int K) {
+  static const std::string v = getenv("VITS_PAIR64") ? getenv("VITS_PAIR64") : "";
+  return ("," + v + ",").find("," + std::to_string(K) + ",") != std::string::npos;
+}
+
+bool pair_profitable(const ConvDesc& c1, const ConvDesc& c2) {
+  return pair_fusable(c1, c2) && (c1.M == 32 || pair64_taps(c1.K));
+}
+
 bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2) {
-  return c1.prec == PREC_F16X2 && c2.prec == PREC_F16X2 && c1.mode == MODE_PLAIN && c2.mode == MODE_PLAIN &&
-         c1.M == 32 && c1.Cin == 32 && c2.M == 32 && c2.Cin == 32 && c1.K == c2.K && (c1.K & 1) && c2.tstep[0] == 1 &&
-         (c1.K - 1) / 2 * c1.tstep[0] <= 25 && (c2.K - 1) / 2 <= PAIR_YOFF;
+  const bool shape = c1.prec == PREC_F16X2 && c2.prec == PREC_F16X2 && c1.mode == MODE_PLAIN && c2.mode == MODE_PLAIN &&
+                     c1.M == c1.Cin && c2.M == c1.M && c2.Cin == c1.M && c1.K == c2.K && (c1.K & 1) && c2.tstep[0] == 1 &&
+                     (c1.K - 1) / 2 * c1.tstep[0] <= 25 && (c2.K - 1) / 2 <= PAIR_YOFF;
+  return shape && (c1.M == 32 || c1.M == 64);
 }
 
 hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const PairArgs& a, hipStream_t stream) {
   if (!pair_fusable(c1, c2) || a.B <= 0 || a.L <= 0 || a.B > 65535) return hipErrorInvalidValue;
-  const int K = c1.K, dil = c1.tstep[0];
-  const int ncols = PAIR_W1 + 2 * ((K - 1) / 2 * dil);
-  const size_t lds = ((size_t)4 * ncols + (size_t)8 * PAIR_W1 + 64) * sizeof(uint4);   // + slack for the invalid n-tile
-  dim3 grid((a.L + PAIR_BN - 1) / PAIR_BN, 1, a.B);
+  const int K = c1.K, dil = c1.tstep[0], MT = c1.M / 32;
+  const int W1 = 64 * (4 / MT), BN = W1 - 32, nch = 2 * MT;
+  const int ncols = W1 + 2 * ((K - 1) / 2 * dil);
+  const size_t lds = ((size_t)4 * ncols + (size_t)nch * 4 * W1 + 64) * sizeof(uint4);   // + slack for the invalid n-tile
+  dim3 grid((a.L + BN - 1) / BN, 1, a.B);
   ConvArgs ta;
   memset(&ta, 0, sizeof ta);
-  ta.M = 32; ta.Cin = 32; ta.K = 2 * K; ta.L = a.L; ta.B = a.B;          // timing row: both convs' FLOPs
+  ta.M = c1.M; ta.Cin = c1.M; ta.K = 2 * K; ta.L = a.L; ta.B = a.B;      // timing row: both convs' FLOPs
   ta.flags = F_RES | (a.accumulate ? F_ACCUM : 0);
   char name[64];
-  snprintf(name, sizeof name, "resblock_pair32_kernel<k%d>", K);
+  snprintf(name, sizeof name, "resblock_pair_kernel<%d,k%d>", MT, K);
   return timed_launch(name, false, ta, stream, [&] {
-    hipLaunchKernelGGL(resblock_pair32_kernel, grid, dim3(256), lds, stream, a, reinterpret_cast<const uint4*>(c1.w), c1.bias,
-                       reinterpret_cast<const uint4*>(c2.w), c2.bias, K, dil);
+    if (MT == 1)
+      hipLaunchKernelGGL(resblock_pair_kernel<1>, grid, dim3(256), lds, stream, a, reinterpret_cast<const uint4*>(c1.w),
+                         c1.bias, reinterpret_cast<const uint4*>(c2.w), c2.bias, K, dil);
+    else
+      hipLaunchKernelGGL(resblock_pair_kernel<2>, grid, dim3(256), lds, stream, a, reinterpret_cast<const uint4*>(c1.w),
+                         c1.bias, reinterpret_cast<const uint4*>(c2.w), c2.bias, K, dil);
   });
 }
 

@@ -818,7 +818,7 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
       const ResBlock& rb = m->rbs[i * nk + j];
       const float* yin = X;
       for (int q = 0; q < nd; ++q) {
-        if (fused_pairs_enabled() && pair_fusable(rb.c1[q], rb.c2[q])) {
+        if (fused_pairs_enabled() && pair_profitable(rb.c1[q], rb.c2[q])) {
           // 32-channel stage: the whole pair in one launch, the tensor between the convs never leaves LDS.  Blocks
           // read a halo of their input, so the pair cannot run in place: Y and T take turns as the chain's carrier.
           const bool last = q + 1 == nd;
@@ -896,7 +896,8 @@ int vits_op_resblock_pair(const void* w1, const float* b1, const void* w2, const
   ConvDesc c1, c2;
   TRY(make_desc(c1, w1, b1, channels, channels, taps, dilation, MODE_PLAIN, PREC_F16X2));
   TRY(make_desc(c2, w2, b2, channels, channels, taps, 1, MODE_PLAIN, PREC_F16X2));
-  if (!pair_fusable(c1, c2)) return fail(VITS_ERR_INVALID, "resblock pair: 32 channels, odd taps, halo <= 25 required");
+  if (!pair_fusable(c1, c2))
+    return fail(VITS_ERR_INVALID, "resblock pair: 32 or 64 channels, odd taps, halo <= 25 required");
   if (x == out) return fail(VITS_ERR_INVALID, "resblock pair: cannot run in place");
   PairArgs pa;
   pa.x = x; pa.x_bs = (long long)channels * L; pa.x_cs = L;
