@@ -77,13 +77,16 @@ def algorithmic_flops(phoneme_counts, frame_counts, predicted_duration=False):
     return sum(837861376 * t + 3072 * t * t + per_p * p + 7680 * p * p for p, t in zip(phoneme_counts, frame_counts))
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` (2 * FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes over
     this benchmark's command (profiles/r01_pmc_traffic.json: the command, the gfx950 FETCH_SIZE correction and its
-    check are recorded there); None when no pass covers the kernel."""
+    check are recorded there); None when no pass covers the kernel or the passes ran on another shape or precision."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes"]
+            table = json.load(f)
+        if table["workload"] != workload:
+            return None
+        return table["kernels"][kernel]["hbm_bytes"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -255,12 +258,13 @@ def main():
         torch.cuda.synchronize(device)
         N.lib.vits_profile_enable(0)
         rows = sorted(N.profile_rows(), key=lambda r: -r["ms"])
-        dom = rows[0]
+        dom = rows[0]                       # rows are named like the kernel symbols a profiler's table lists
         conv_ms = sum(r["ms"] for r in rows)
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         peak = (PEAK_FP32_MFMA_TFLOPS if dom["name"].startswith("conv_mfma_kernel") else
                 PEAK_BF16_MFMA_TFLOPS if dom["name"].startswith("conv_bf16_kernel") else
-                PEAK_F16X2_TFLOPS if dom["name"].startswith("conv_f16x2_kernel") else PEAK_BF16X3_TFLOPS)
+                PEAK_F16X2_TFLOPS if dom["name"].startswith(("conv_f16x2_kernel", "resblock_pair_kernel")) else
+                PEAK_BF16X3_TFLOPS)
         gbps = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
         # the bound is whichever roof the kernel's arithmetic intensity puts lower: the plain-bf16 generator layers
         # (64 / 32 channels) sit under the HBM roof, the fp32-grade modes under the MFMA roof
@@ -271,7 +275,8 @@ def main():
         else:
             roof = dict(bound="mfma", kernel=dom["name"], achieved=round(achieved, 3), peak=round(peak, 1),
                         unit="TFLOP/s", frac=round(achieved / peak, 4), algorithmic_gbps=round(gbps, 1))
-        roofline = dict(roof, traffic=pmc_traffic(dom["name"]),
+        roofline = dict(roof, traffic=pmc_traffic(dom["name"], dict(batch=args.batch, frames=args.frames, phonemes=args.phonemes,
+                                                              precision=net.precision)),
                         algorithmic_bytes_per_launch=round(dom["bytes"] / dom["count"]),
                         launches_per_step=dom["count"] // args.steps,
                         avg_launch_us=round(dom["ms"] * 1e3 / dom["count"], 2),

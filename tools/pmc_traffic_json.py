@@ -16,7 +16,7 @@ import sys
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and "vits::conv_" in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and ("vits::conv_" in r["Kernel_Name"] or "vits::resblock_pair" in r["Kernel_Name"]):
             name = r["Kernel_Name"].replace("void ", "").replace("vits::", "").split("(")[0]
             name = re.sub(r"\s+", "", name)
             # the library's timing rows call the staged-input instantiations "...,staged>" and leave "false" out
@@ -34,7 +34,13 @@ def main():
         f = sum(rd[k]) / len(rd[k])
         w = sum(wr[k]) / len(wr[k]) if k in wr else 0.0
         kernels[k] = dict(launches=len(rd[k]), fetch_size_raw=round(f), write_size=round(w), hbm_bytes=round(2 * f + w))
-    json.dump(dict(command=cmd,
+    # the shape the passes ran on: bench.py attaches these bytes to its roofline only when it runs the same shape
+    def opt(flag, default):
+        m = re.search(flag + r"[ =](\S+)", cmd)
+        return type(default)(m.group(1)) if m else default
+    workload = dict(batch=opt("--batch", 16), frames=opt("--frames", 258), phonemes=opt("--phonemes", 50),
+                    precision=opt("--precision", "f16x2"))
+    json.dump(dict(command=cmd, workload=workload,
                    units="bytes per launch (mean over the run's launches of that kernel); hbm_bytes = 2 * FETCH_SIZE + "
                          "WRITE_SIZE: FETCH_SIZE counts 128-byte read requests as 64 bytes on gfx950 (checked on a conv of "
                          "known traffic: reported 306 MB against 541 MB read, 598 MB after doubling; WRITE_SIZE matched "

@@ -1146,7 +1146,7 @@ static hipError_t timed_launch(const char* name, bool gate, const ConvArgs& a, h
     // accumulated-output reads where the epilogue has them, the packed weights once
     const double outs = (gate ? 0.5 : 1.0) * a.M;
     const int reads = ((a.flags & (F_RES | F_RES_SUB)) ? 1 : 0) + ((a.flags & F_ACCUM) ? 1 : 0);
-    const double wbytes = strstr(name, "conv_mfma") || strstr(name, "conv_f16x2") ? 4.0
+    const double wbytes = strstr(name, "conv_mfma") || strstr(name, "conv_f16x2") || strstr(name, "resblock_pair") ? 4.0
                           : strstr(name, "conv_bf16_kernel") ? 2.0 : 6.0;
     const double sb = strstr(name, "conv_bf16_kernel") ? 2.0 : 4.0;           // bytes per staged element
     const double in_b = (a.flags & F_IN_STAGED) ? sb : 4.0, out_b = (a.flags & F_OUT_STAGED) ? sb : 4.0;
@@ -1597,12 +1597,20 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
 constexpr int PAIR_YOFF = 16;
 
 // MT = channels / 32: MT waves side by side in rows (one 32-row tile each), 4 / MT in time (64 steps each).
-template <int MT>
+// Three blocks to a CU: a fourth (Y overlaid on the dead x tile, 128 registers) measured 4 to 11 % slower.
+// K (taps) is a template parameter so that both tap loops unroll completely: the weight fragments of the next PAIR_AHEAD
+// taps are then kept in flight in a register ring with compile-time slots.  A fragment load is an L2 hit, but vector
+// memory returns in order within a CU, so behind the other blocks' streaming x loads it takes ~2000 cycles instead of
+// ~560; fetched only one tap ahead of its MFMAs (192 cycles a tap) the matrix pipe sat idle most of the time.
+constexpr int PAIR_AHEAD = 3;
+
+template <int MT, int K>
 __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a, const uint4* __restrict__ w1,
                                                                const float* __restrict__ b1,
                                                                const uint4* __restrict__ w2,
-                                                               const float* __restrict__ b2, int K, int dil) {
+                                                               const float* __restrict__ b2, int dil) {
   constexpr int WGN = 4 / MT, W1 = 64 * WGN, BN = W1 - 32, NCH = 2 * MT;
+  constexpr int NT = NCH * K, D = PAIR_AHEAD;               // taps per conv; depth of the weight ring
   constexpr int NCT = (W1 + 50 + 255) / 256;                // x-tile columns per thread
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1673,18 +1681,45 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
                                                       acc[j], 0, 0, 0);
   };
 
+  // weight ring: tap g of the virtual sequence [first conv's NT taps, second conv's NT taps] lives in slot g % D
+  uint4 Aq[D][2];
+  auto fetch_a = [&](int g) __attribute__((always_inline)) {
+    if (g < 2 * NT) {
+      const uint4* wk = (g < NT ? w1 : w2) + ((long long)(g < NT ? g : g - NT) * MT + wm) * 128 + lane;
+      Aq[g % D][0] = wk[0];
+      Aq[g % D][1] = wk[64];
+    }
+  };
+#pragma unroll
+  for (int g = 0; g < D; ++g) fetch_a(g);
+
   // ---- first conv: rows 32 * wm .., Y columns [64 * wn, 64 * wn + 64) ----
   zero_acc();
   load_chunk(0);
+  // The residual (x at this lane's output positions) is fetched as soon as the staging registers are free (after the
+  // last chunk of the x tile has gone to LDS), while the tile's cache lines are still in L2, and held in registers to
+  // the end: by the epilogue those lines have long been evicted and the second read of x went to memory again
+  // (measured: 270 MB of 970 MB per launch).
+  float rv[2][16];
+  auto load_residual = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = t0 + wn * 64 + j * 32 + l31;
+      const int tc = t < a.L ? t : a.L - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        rv[j][r] = xb[(long long)(32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)) * a.x_cs + tc];
+    }
+  };
   store_chunk();
   __syncthreads();
   {
     const int colbase = wn * 64 + l31 + par * ncols;
-    for (int chunk = 0; chunk < NCH; ++chunk) {
-      if (chunk + 1 < NCH) load_chunk(chunk + 1);
+    auto taps = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
       for (int k = 0; k < K; ++k) {
-        const uint4* wk = w1 + ((long long)(chunk * K + k) * MT + wm) * 128 + lane;
-        const uint4 Ah = wk[0], Al = wk[64];
+        const int g = chunk * K + k;
+        const uint4 Ah = Aq[g % D][0], Al = Aq[g % D][1];
         const int off = colbase + k * dil;
         uint4 Bh[2], Bl[2];
 #pragma unroll
@@ -1695,13 +1730,19 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
         mma(Ah, Bl);                                       // h * l
         mma(Ah, Bh);                                       // h * h
         mma(Al, Bh);                                       // l * h
+        fetch_a(g + D);
       }
-      if (chunk + 1 < NCH) {
-        __syncthreads();
-        store_chunk();
-        __syncthreads();
-      }
+    };
+#pragma unroll
+    for (int chunk = 0; chunk + 1 < NCH; ++chunk) {
+      load_chunk(chunk + 1);
+      taps(chunk);
+      __syncthreads();
+      store_chunk();
+      __syncthreads();
     }
+    load_residual();                                       // the staging registers are free from here on
+    taps(NCH - 1);
   }
   // ---- Y = split(lrelu(c1 + bias)), zero outside the sequence; 8-byte pieces (four channels of a half) ----
   {
@@ -1743,10 +1784,12 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
   zero_acc();
   {
     const int obase = wn * 64 + l31 + PAIR_YOFF - h2 + par * W1;
+#pragma unroll
     for (int chunk = 0; chunk < NCH; ++chunk)
+#pragma unroll
       for (int k = 0; k < K; ++k) {
-        const uint4* wk = w2 + ((long long)(chunk * K + k) * MT + wm) * 128 + lane;
-        const uint4 Ah = wk[0], Al = wk[64];
+        const int g = NT + chunk * K + k;
+        const uint4 Ah = Aq[g % D][0], Al = Aq[g % D][1];
         const int off = (chunk * 4) * W1 + obase + k;
         uint4 Bh[2], Bl[2];
 #pragma unroll
@@ -1757,12 +1800,13 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
         mma(Ah, Bl);
         mma(Ah, Bh);
         mma(Al, Bh);
+        fetch_a(g + D);
       }
   }
   // ---- out = c2 + bias + x (+ out); all loads of the tile before its first store ----
   {
     float* ob = a.out + (long long)b * a.out_bs;
-    float bz[16], rv[2][16], ov[2][16];
+    float bz[16], ov[2][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bz[r] = b2 ? b2[32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
 #pragma unroll
@@ -1772,7 +1816,6 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * wm + 4 * par + (r & 3) + 8 * (r >> 2);
-        rv[j][r] = xb[(long long)row * a.x_cs + tc];
         ov[j][r] = a.accumulate ? ob[(long long)row * a.out_cs + tc] : 0.f;
       }
     }
@@ -1793,12 +1836,13 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
   }
 }
 
-// Where the fused pair is the faster choice (measured at 16 x 3 s): every 32-channel pair (k = 3: 217 against 363 us,
-// k = 7: 312 / 372, k = 11: 401 / 442).  At 64 channels the tile is 96 steps wide (the intermediate has to fit in LDS
-// three blocks to a CU), and the halo re-reads and the wider first conv eat the saved traffic: k = 3 equal, k = 7 and 11
-// slower.  VITS_PAIR64=3,7 (a list of tap counts) turns it on there for measurements.
+// Where the fused pair is the faster choice (measured at 16 x 3 s, per launch): every 32-channel pair (k = 3: 190 us
+// against 363 for the two launches, k = 7: 277 / 372, k = 11: 363 / 442).  At 64 channels the tile is 96 steps wide (the
+// intermediate has to fit in LDS three blocks to a CU), and the halo re-reads and the wider first conv eat the saved
+// traffic: k = 3 wins (300 / 346), k = 7 and 11 lose (557 and 806 us against ~590 for both).  VITS_PAIR64 (a list of
+// tap counts, default "3"; empty for none) chooses the 64-channel pairs that are fused.
 static bool pair64_taps(int K) {
-  static const std::string v = getenv("VITS_PAIR64") ? getenv("VITS_PAIR64") : "";
+  static const std::string v = getenv("VITS_PAIR64") ? getenv("VITS_PAIR64") : "3";
   return ("," + v + ",").find("," + std::to_string(K) + ",") != std::string::npos;
 }
 
@@ -1810,7 +1854,7 @@ bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2) {
   const bool shape = c1.prec == PREC_F16X2 && c2.prec == PREC_F16X2 && c1.mode == MODE_PLAIN && c2.mode == MODE_PLAIN &&
                      c1.M == c1.Cin && c2.M == c1.M && c2.Cin == c1.M && c1.K == c2.K && (c1.K & 1) && c2.tstep[0] == 1 &&
                      (c1.K - 1) / 2 * c1.tstep[0] <= 25 && (c2.K - 1) / 2 <= PAIR_YOFF;
-  return shape && (c1.M == 32 || c1.M == 64);
+  return shape && (c1.M == 32 || c1.M == 64) && c1.K >= 3 && c1.K <= 11;
 }
 
 hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const PairArgs& a, hipStream_t stream) {
@@ -1823,16 +1867,27 @@ hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const Pa
   ConvArgs ta;
   memset(&ta, 0, sizeof ta);
   ta.M = c1.M; ta.Cin = c1.M; ta.K = 2 * K; ta.L = a.L; ta.B = a.B;      // timing row: both convs' FLOPs
-  ta.flags = F_RES | (a.accumulate ? F_ACCUM : 0);
+  ta.flags = a.accumulate ? F_ACCUM : 0;       // bytes: x once (the residual is the same tensor), the result, the sum
   char name[64];
-  snprintf(name, sizeof name, "resblock_pair_kernel<%d,k%d>", MT, K);
+  snprintf(name, sizeof name, "resblock_pair_kernel<%d,%d>", MT, K);
+  const uint4* w1 = reinterpret_cast<const uint4*>(c1.w);
+  const uint4* w2 = reinterpret_cast<const uint4*>(c2.w);
+  auto go = [&](auto mt, auto kk) {
+    hipLaunchKernelGGL((resblock_pair_kernel<decltype(mt)::value, decltype(kk)::value>), grid, dim3(256), lds, stream, a,
+                       w1, c1.bias, w2, c2.bias, dil);
+  };
+  auto by_taps = [&](auto mt) {
+    switch (K) {
+      case 3: go(mt, IntC<3>{}); break;
+      case 5: go(mt, IntC<5>{}); break;
+      case 7: go(mt, IntC<7>{}); break;
+      case 9: go(mt, IntC<9>{}); break;
+      default: go(mt, IntC<11>{}); break;
+    }
+  };
   return timed_launch(name, false, ta, stream, [&] {
-    if (MT == 1)
-      hipLaunchKernelGGL(resblock_pair_kernel<1>, grid, dim3(256), lds, stream, a, reinterpret_cast<const uint4*>(c1.w),
-                         c1.bias, reinterpret_cast<const uint4*>(c2.w), c2.bias, K, dil);
-    else
-      hipLaunchKernelGGL(resblock_pair_kernel<2>, grid, dim3(256), lds, stream, a, reinterpret_cast<const uint4*>(c1.w),
-                         c1.bias, reinterpret_cast<const uint4*>(c2.w), c2.bias, K, dil);
+    if (MT == 1) by_taps(IntC<1>{});
+    else by_taps(IntC<2>{});
   });
 }
 
