@@ -166,7 +166,8 @@ int vits_op_conv1d(const void* packed_w, const float* bias_rows, int cin, int ro
                    void* stream);
 /* One ResBlock1 pair (reference modules.py:206-219, one iteration of its loop) in a single launch:
  * out = x + conv2(lrelu(conv1(lrelu(x)))) (+ out when accumulate), conv1 dilated, conv2 dilation 1, both with `taps`
- * taps and f16x2-packed weights [C][C][taps]; C = 32 or 64; x and out [B, C, L], not overlapping. */
+ * taps (3, 5, 7, 9 or 11; (taps - 1) / 2 * dilation <= 25) and f16x2-packed weights [C][C][taps]; C = 32 or 64;
+ * x and out [B, C, L], not overlapping.  Anything else is VITS_ERR_INVALID. */
 int vits_op_resblock_pair(const void* packed_w1, const float* bias1, const void* packed_w2, const float* bias2,
                           int channels, int taps, int dilation, const float* x, float* out, int B, int L,
                           int accumulate, float slope, void* stream);

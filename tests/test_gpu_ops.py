@@ -211,7 +211,9 @@ def test_conv_staged_pair(N, pname, C, k, dil, L, B):
 @pytest.mark.parametrize("C,k,dil,L,B,acc", [(32, 3, 1, 1000, 2, False), (32, 7, 3, 3000, 2, True),
                                              (32, 11, 5, 2500, 3, False), (32, 11, 1, 224, 1, True),
                                              (32, 3, 5, 225, 2, False), (32, 7, 5, 50, 2, False),
-                                             (64, 3, 1, 1000, 2, True), (64, 7, 5, 97, 3, False), (64, 11, 3, 96, 1, False)])
+                                             (64, 3, 1, 1000, 2, True), (64, 7, 5, 97, 3, False), (64, 11, 3, 96, 1, False),
+                                             (32, 5, 3, 700, 2, True), (32, 9, 1, 449, 2, False),
+                                             (64, 5, 5, 193, 2, False), (64, 9, 3, 300, 1, True)])
 def test_resblock_pair_fused(N, C, k, dil, L, B, acc):
     """The fused ResBlock pair (32 or 64 channels; tensor between the convs kept in LDS) against
     the two separate f16x2 convs: same operands in the same order, so the same bytes -- across tile borders (224- and
@@ -244,6 +246,20 @@ def test_resblock_pair_fused(N, C, k, dil, L, B, acc):
     y = F.conv1d(F.leaky_relu(xc, 0.1), w1, b1.cpu(), padding=(k - 1) // 2 * dil, dilation=dil)
     y = F.conv1d(F.leaky_relu(y, 0.1), w2, b2.cpu(), padding=(k - 1) // 2) + xc + (init.cpu() if acc else 0)
     assert (out.cpu() - y).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("C,k,dil", [(32, 13, 1), (32, 4, 1), (32, 11, 6), (96, 3, 1), (32, 1, 1)])
+def test_resblock_pair_refuses_unsupported_shapes(N, C, k, dil):
+    """Tap counts without an instantiation (odd, 3..11), a first-conv halo over 25 steps and other channel counts
+    are an error, never a launch."""
+    from vits_amd import weights
+    p = PREC["f16x2"]
+    w = torch.zeros(C, C, k)
+    pk, b = dev(weights.pack_rows(w, p)), dev(torch.zeros(C))
+    x, out = dev(torch.zeros(1, C, 64)), dev(torch.zeros(1, C, 64))
+    rc = N.lib.vits_op_resblock_pair(pk.data_ptr(), b.data_ptr(), pk.data_ptr(), b.data_ptr(), C, k, dil,
+                                     x.data_ptr(), out.data_ptr(), 1, 64, 0, 0.1, torch.cuda.current_stream().cuda_stream)
+    assert rc != 0
 
 
 @pytest.mark.parametrize("C,L,mask", [(192, 50, False), (256, 333, True), (768, 70, False), (192, 1, True)])

@@ -897,7 +897,7 @@ int vits_op_resblock_pair(const void* w1, const float* b1, const void* w2, const
   TRY(make_desc(c1, w1, b1, channels, channels, taps, dilation, MODE_PLAIN, PREC_F16X2));
   TRY(make_desc(c2, w2, b2, channels, channels, taps, 1, MODE_PLAIN, PREC_F16X2));
   if (!pair_fusable(c1, c2))
-    return fail(VITS_ERR_INVALID, "resblock pair: 32 or 64 channels, odd taps, halo <= 25 required");
+    return fail(VITS_ERR_INVALID, "resblock pair: 32 or 64 channels, 3 / 5 / 7 / 9 / 11 taps, first-conv halo <= 25 required");
   if (x == out) return fail(VITS_ERR_INVALID, "resblock pair: cannot run in place");
   PairArgs pa;
   pa.x = x; pa.x_bs = (long long)channels * L; pa.x_cs = L;
