@@ -87,6 +87,25 @@ def test_conv_plain(N, prec, cout, cin, k, dil, B, L):
     assert (got - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("C,k,dil,L", [(64, 7, 3, 12000), (128, 3, 1, 6000), (256, 11, 1, 3000)])
+def test_conv_f16x2_small_and_large_grids_agree(N, C, k, dil, L):
+    """The f16x2 kernel has two builds of its 64-row-tile configurations: one for grids that fill the chip (three
+    blocks per CU) and one for small grids (weight fragments of the next taps kept in flight in registers).  A batch of
+    16 goes to the first, its rows one at a time to the second; the bytes must be the same, and right against fp32."""
+    p = PREC["f16x2"]
+    g = torch.Generator().manual_seed(C + k + L)
+    B = 16
+    w = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    b = torch.randn(C, generator=g)
+    x = torch.randn(B, C, L, generator=g)
+    whole = gpu_conv(N, w, b, x, dilation=dil, prec=p)
+    for i in (0, 7, 15):
+        row = gpu_conv(N, w, b, x[i:i + 1], dilation=dil, prec=p)
+        assert torch.equal(row[0], whole[i])
+    ref = F.conv1d(x[:2], w, b, padding=(k - 1) // 2 * dil, dilation=dil)
+    assert (whole[:2] - ref).abs().max() < 2e-5
+
+
 def test_conv_prologue_epilogue_flags(N, prec):
     g = torch.Generator().manual_seed(7)
     cout, cin, k, B, L = 64, 48, 3, 3, 333

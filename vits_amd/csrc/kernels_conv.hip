@@ -918,8 +918,13 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
 // a relative error per product of about 2^-22 instead of 2^-24.  Activations are clamped to the fp16 range
 // (+-65504) at staging.  Weights: [Cin/16][tap][M/32][2 planes][64 lanes][8 fp16]; LDS [2 planes][2 halves][ncols].
 // ---------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int WGM, int WGN, int MODE, bool STG = false>
-__global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(const ConvArgs a) {
+// RING > 0: the variant for launches that cannot fill the chip (at most two blocks per CU).  There a block is one
+// serial chain whose every tap waits for its weight fragments, and with few blocks per XCD those come from beyond L2
+// (~1800 cycles a tap measured at batch 1, against 384 cycles of MFMAs).  The variant keeps the fragments of the next
+// RING taps in flight in a register ring (slots are compile-time: the tap loop is flat and unrolled RING times) and
+// spends the registers that occupancy does not need.  Same operands in the same order: bit-identical results.
+template <int WM, int WN, int WGM, int WGN, int MODE, bool STG = false, int RING = 0>
+__global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(const ConvArgs a) {
   constexpr int BN = 32 * WN * WGN;
   constexpr int NCT = (BN + MAX_HALO + 255) / 256;       // tile columns per thread
   constexpr bool TWO_CLASS = (MODE == MODE_UP8 || MODE == MODE_UP2);
@@ -1042,11 +1047,22 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(co
   const long long it_stride = (long long)a.mt_total * 128;
   const int nchunks = a.Cin / 16;
   const int n_it = nchunks * a.K;
+  constexpr int D = RING > 0 ? RING : 1;
   uint4 A[2][WM], An[2][WM];      // planes h, l of the current and of the next tap
+  uint4 Aq[D][2][WM];             // RING: planes h, l of the next D taps, tap i in slot i % D
+  auto fetch_a = [&](int itx, uint4 (&dst)[2][WM]) __attribute__((always_inline)) {
+    const long long o = (long long)(itx < n_it ? itx : n_it - 1) * it_stride;
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int i = 0; i < WM; ++i) A[p][i] = wp[i][p * 64];
+      for (int i = 0; i < WM; ++i) dst[p][i] = wp[i][o + p * 64];
+  };
+  if constexpr (RING > 0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch_a(d, Aq[d]);
+  } else {
+    fetch_a(0, A);
+  }
   int it = 0;
 
   load_chunk(0);
@@ -1074,6 +1090,47 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(co
   // The next tap's weight fragments (L2) are requested at the top of a tap into a second register set; each
   // activation plane (LDS) is refetched right after its last use.  All reloads are unconditional (a chunk's last tap
   // re-reads its own activation fragments, the last tap of all its own weights): straight-line code, exact waits.
+  if constexpr (RING > 0) {
+    int chunk = 0, k = 0;
+    int boff[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) boff[c] = colbase + a.toff0[c];
+    if (nchunks > 1) load_chunk(1);
+    ldb(0, boff);
+    ldb(1, boff);
+    for (int it0 = 0; it0 < n_it; it0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (it0 + d < n_it) {
+          int boffn[NB];
+#pragma unroll
+          for (int c = 0; c < NB; ++c) boffn[c] = k + 1 < a.K ? boff[c] + a.tstep[c] : boff[c];
+          mma(Aq[d][0], B[1]);                             // h * l
+          ldb(1, boffn);
+          mma(Aq[d][0], B[0]);                             // h * h
+          mma(Aq[d][1], B[0]);                             // l * h
+          ldb(0, boffn);
+          fetch_a(it0 + d + D, Aq[d]);
+#pragma unroll
+          for (int c = 0; c < NB; ++c) boff[c] = boffn[c];
+          if (++k == a.K) {
+            k = 0;
+            ++chunk;
+            if (chunk < nchunks) {
+              __syncthreads();
+              store_chunk(chunk);
+              __syncthreads();
+              if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+#pragma unroll
+              for (int c = 0; c < NB; ++c) boff[c] = colbase + a.toff0[c];
+              ldb(0, boff);
+              ldb(1, boff);
+            }
+          }
+        }
+      }
+    }
+  } else
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     if (chunk + 1 < nchunks) load_chunk(chunk + 1);
     int boff[NB];
@@ -1211,6 +1268,18 @@ static hipError_t launch_b1(ConvArgs& a, hipStream_t stream) {
   });
 }
 
+constexpr int F16X2_RING = 6;
+int device_cu_count();
+// The ring variant takes grids of at most VITS_CONV_RING blocks per CU (default 2, what its register count lets be
+// resident; 0 keeps every launch on the occupancy-oriented kernel, for A/B measurements).
+static int f16x2_ring_blocks_per_cu() {
+  static const int n = [] {
+    const char* e = getenv("VITS_CONV_RING");
+    return e && e[0] ? atoi(e) : 2;
+  }();
+  return n;
+}
+
 template <int WM, int WN, int WGM, int WGN, int MODE>
 static hipError_t launch_h2(ConvArgs& a, hipStream_t stream) {
   constexpr int BN = 32 * WN * WGN;
@@ -1220,6 +1289,22 @@ static hipError_t launch_h2(ConvArgs& a, hipStream_t stream) {
   dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
   const size_t lds = (size_t)4 * a.rs * sizeof(uint4);
   char name[96];
+  if constexpr (MODE == MODE_PLAIN && WM == 2 && WN == 2) {
+    // a grid of at most two blocks per CU is a set of serial chains: the weight-ring variant
+    if ((long long)grid.x * grid.y * grid.z <= (long long)f16x2_ring_blocks_per_cu() * device_cu_count()) {
+      const bool stg = a.flags & F_IN_STAGED;
+      snprintf(name, sizeof name, "conv_f16x2_kernel<%d,%d,%d,%d,%d,%s,%d>", WM, WN, WGM, WGN, MODE,
+               stg ? "staged" : "false", F16X2_RING);
+      return timed_launch(name, false, a, stream, [&] {
+        if (stg)
+          hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, WGM, WGN, MODE, true, F16X2_RING>), grid, dim3(256), lds,
+                             stream, a);
+        else
+          hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, WGM, WGN, MODE, false, F16X2_RING>), grid, dim3(256), lds,
+                             stream, a);
+      });
+    }
+  }
   if constexpr (MODE == MODE_PLAIN) {
     if (a.flags & F_IN_STAGED) {
       snprintf(name, sizeof name, "conv_f16x2_kernel<%d,%d,%d,%d,%d,staged>", WM, WN, WGM, WGN, MODE);
