@@ -20,7 +20,10 @@ def per_kernel(path, counter):
             name = r["Kernel_Name"].replace("void ", "").replace("vits::", "").split("(")[0]
             name = re.sub(r"\s+", "", name)
             # the library's timing rows call the staged-input instantiations "...,staged>" and leave "false" out
-            name = name.replace(",true>", ",staged>").replace(",false>", ">")
+            # (and the small-grid build "...,staged,6>" / "...,false,6>"; the profiler prints the template arguments
+            # "true|false, ring")
+            name = re.sub(r",true,(\d+)>", lambda m: ",staged>" if m.group(1) == "0" else f",staged,{m.group(1)}>", name)
+            name = name.replace(",false,0>", ">").replace(",true>", ",staged>").replace(",false>", ">")
             acc[name].append(float(r["Counter_Value"]) * 1024.0)
     return acc
 
