@@ -505,6 +505,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
       const int col = tid + 256 * q, t = tstart + col;
+      if (col - lane >= wcols) continue;              // none of this wave's columns is in the tile: no requests
       const bool ok = col < wcols && t >= 0 && t < a.L;
       const float* xc = xb + (long long)chunk * 16 * a.x_cs + (ok ? t : 0);
 #pragma unroll
@@ -768,6 +769,7 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
 #pragma unroll
       for (int q = 0; q < NCT; ++q) {
         const int col = tid + 256 * q, t = tstart + col;
+        if (col - lane >= wcols) continue;              // none of this wave's columns is in the tile: no requests
         const bool ok = col < wcols && t >= 0 && t < a.L;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -780,6 +782,7 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
       const int col = tid + 256 * q, t = tstart + col;
+      if (col - lane >= wcols) continue;              // none of this wave's columns is in the tile: no requests
       const bool ok = col < wcols && t >= 0 && t < a.L;
       const float* xc = xb + (long long)chunk * 16 * a.x_cs + (ok ? t : 0);
 #pragma unroll
@@ -960,6 +963,7 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
 #pragma unroll
       for (int q = 0; q < NCT; ++q) {
         const int col = tid + 256 * q, t = tstart + col;
+        if (col - lane >= wcols) continue;              // none of this wave's columns is in the tile: no requests
         const bool ok = col < wcols && t >= 0 && t < a.L;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -972,6 +976,7 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
       const int col = tid + 256 * q, t = tstart + col;
+      if (col - lane >= wcols) continue;              // none of this wave's columns is in the tile: no requests
       const bool ok = col < wcols && t >= 0 && t < a.L;
       const float* xc = xb + (long long)chunk * 16 * a.x_cs + (ok ? t : 0);
 #pragma unroll
@@ -1371,6 +1376,7 @@ __global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const C
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
       const int col = lane + 64 * q, t = tstart + col;
+      if (64 * q >= wcols) continue;                   // narrow tile: this column slot is empty for every lane
       const unsigned toff = (col < wcols && t >= 0 && t < a.L) ? (unsigned)t : 0u;
       const float* xc = xb + (long long)chunk * 16 * a.x_cs;
 #pragma unroll
@@ -1381,6 +1387,7 @@ __global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const C
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
       const int col = lane + 64 * q, t = tstart + col;
+      if (64 * q >= wcols) continue;
       bool ok = t >= 0 && t < a.L;
       if (a.flags & F_IN_MASK) ok = ok && t < len_b;
       unsigned ph[8], pm[8], pl[8];
@@ -1715,6 +1722,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
       const int col = tid + 256 * q, t = tx0 + col;
+      if (col - lane >= ncols) continue;               // none of this wave's columns is in the tile: no requests
       const bool ok = col < ncols && t >= 0 && t < a.L;
       const float* xc = xb + (long long)chunk * 16 * a.x_cs + (ok ? t : 0);
 #pragma unroll
