@@ -667,6 +667,8 @@ hipError_t launch_lr_plan(const void* dur, int dur_dtype, int B, int P, int* cum
   return hipGetLastError();
 }
 
+constexpr int LR_CH_PER_BLOCK = 16;
+
 __global__ __launch_bounds__(256) void lr_gather_kernel(const float* __restrict__ x, const int* __restrict__ cum,
                                                          const int* __restrict__ totals, float* __restrict__ out, int C,
                                                          int P, int T) {
@@ -686,15 +688,21 @@ __global__ __launch_bounds__(256) void lr_gather_kernel(const float* __restrict_
     }
     src = lo;
   }
+  // blockIdx.z: a group of LR_CH_PER_BLOCK channels (a thread walking all channels alone is one long chain of loads:
+  // 44 us for one 3-second utterance)
+  const int c0 = blockIdx.z * LR_CH_PER_BLOCK, c1 = c0 + LR_CH_PER_BLOCK < C ? c0 + LR_CH_PER_BLOCK : C;
   const float* xb = x + (long long)b * C * P;
   float* ob = out + (long long)b * C * T + t;
-  for (int c = 0; c < C; ++c) ob[(long long)c * T] = src >= 0 ? xb[(long long)c * P + src] : 0.f;
+#pragma unroll 8
+  for (int c = c0; c < c1; ++c) ob[(long long)c * T] = src >= 0 ? xb[(long long)c * P + src] : 0.f;
 }
 
 hipError_t launch_lr_gather(const float* x, const int* cum, const int* totals, float* out, int B, int C, int P, int T,
                             hipStream_t s) {
   if (B <= 0 || P <= 0 || P > LR_MAX_P || T <= 0 || B > 65535) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(lr_gather_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, x, cum, totals, out, C, P, T);
+  if (C <= 0 || (C + LR_CH_PER_BLOCK - 1) / LR_CH_PER_BLOCK > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lr_gather_kernel, dim3((T + 255) / 256, B, (C + LR_CH_PER_BLOCK - 1) / LR_CH_PER_BLOCK), dim3(256), 0,
+                     s, x, cum, totals, out, C, P, T);
   return hipGetLastError();
 }
 
