@@ -1335,8 +1335,11 @@ static hipError_t launch_h2(ConvArgs& a, hipStream_t stream) {
 // block barrier at all, and the chain is a quarter as long.  The four partial accumulators are then summed through LDS
 // in a fixed order ((w0 + w2) + (w1 + w3)) and wave 0 runs the epilogue.
 // ---------------------------------------------------------------------------------------------------------
-template <int WN, int MODE>
-__global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const ConvArgs a) {
+// NW = waves per block that share the reduction: 4, or 8 (WN = 1 only) for the deepest reductions on the smallest
+// grids (768 channels at phoneme rate: six blocks on the chip, so the chain length is all that counts).
+template <int WN, int MODE, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const ConvArgs a) {
+  static_assert(NW == 4 || (NW == 8 && WN == 1), "eight waves: one n-tile");
   constexpr int WM = 2;
   constexpr int BN = 32 * WN;
   constexpr int NCT = (BN + MAX_HALO + 63) / 64;             // tile columns per lane
@@ -1427,7 +1430,7 @@ __global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const C
   for (int i = 0; i < WM; ++i) wofs[i] = (unsigned)(mt[i] * 192 + lane);
   const long long it_stride = (long long)a.mt_total * 192;
   const int nchunks = a.Cin / 16;
-  const int my_chunks = nchunks > wave ? (nchunks - wave + 3) / 4 : 0;
+  const int my_chunks = nchunks > wave ? (nchunks - wave + NW - 1) / NW : 0;
   const int colbase = l31 + par * ncols - a.min_off;
 
   uint4 Ah[2][WM], Am[2][WM], Al[WM], Bh[2][WN], Bm[2][WN], Bl[WN];
@@ -1456,7 +1459,7 @@ __global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const C
     lda(Al, w0, 2);
     load_chunk(chunk);
     store_chunk();
-    if (chunk + 4 < nchunks) load_chunk(chunk + 4);
+    if (chunk + NW < nchunks) load_chunk(chunk + NW);
     ldb(Bh[0], 0, boff);
     ldb(Bm[0], 1, boff);
     ldb(Bl, 2, boff);
@@ -1466,7 +1469,7 @@ __global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const C
       constexpr int c = decltype(P)::value, n = c ^ 1;
       const bool last = k == a.K - 1;
       // next tap: the same chunk, or tap 0 of this wave's next chunk (clamped to the last one at the very end)
-      const int nchunk = last ? (chunk + 4 < nchunks ? chunk + 4 : chunk) : chunk;
+      const int nchunk = last ? (chunk + NW < nchunks ? chunk + NW : chunk) : chunk;
       const int nk = last ? 0 : k + 1;
       const long long wb = ((long long)nchunk * a.K + nk) * it_stride;
       const int boffn = last ? boff : boff + a.tstep[0];
@@ -1494,12 +1497,12 @@ __global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const C
       boff = boffn;
       if (last) {
         // this wave's LDS region is free (its reads were consumed by the MFMAs above): stage the next chunk
-        const bool more = chunk + 4 < nchunks;
-        chunk += 4;
+        const bool more = chunk + NW < nchunks;
+        chunk += NW;
         boff = colbase + a.toff0[0];
         if (more) {
           store_chunk();
-          if (chunk + 4 < nchunks) load_chunk(chunk + 4);
+          if (chunk + NW < nchunks) load_chunk(chunk + NW);
           ldb(Bh[n], 0, boff);
           ldb(Bm[n], 1, boff);
           ldb(Bl, 2, boff);
@@ -1517,7 +1520,7 @@ __global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const C
 
   // ---- fixed-order reduction of the four partial sums through LDS: (w0 + w2) + (w1 + w3) ----
   __syncthreads();                                              // every wave is done with its staging region
-  float* red = reinterpret_cast<float*>(xq);                    // [2 slots][WM * WN * 16][64 lanes]
+  float* red = reinterpret_cast<float*>(xq);                    // [NW / 2 slots][WM * WN * 16][64 lanes]
   constexpr int NACC = WM * WN * 16;
   auto put = [&](int slot) {
 #pragma unroll
@@ -1535,7 +1538,13 @@ __global__ __launch_bounds__(256, WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const C
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(slot * NACC + (i * WN + j) * 16 + r) * 64 + lane];
   };
-  if (wave >= 2) put(wave - 2);
+  if constexpr (NW == 8) {                                      // waves 4..7 into 0..3 first, then as with four
+    if (wave >= 4) put(wave - 4);
+    __syncthreads();
+    if (wave < 4) add(wave);
+    __syncthreads();
+  }
+  if (wave == 2 || wave == 3) put(wave - 2);
   __syncthreads();
   if (wave < 2) add(wave);
   __syncthreads();
@@ -1566,24 +1575,35 @@ static bool ks_enabled() {
   return on;
 }
 
-template <int WN, int MODE>
+template <int WN, int MODE, int NW = 4>
 static hipError_t launch_b3ks(ConvArgs& a, hipStream_t stream) {
   constexpr int BN = 32 * WN;
   a.width = BN + (a.width);
   a.rs = a.width;
   const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + 1) / 2;
   dim3 grid((a.L + BN - 1) / BN, units, a.B);
-  const size_t stage = (size_t)4 * 6 * a.rs * sizeof(uint4), red = (size_t)WN * 16384;
+  const size_t stage = (size_t)NW * 6 * a.rs * sizeof(uint4), red = (size_t)WN * 16384 * (NW / 4);
   const size_t lds = stage > red ? stage : red;
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
   char name[96];
-  snprintf(name, sizeof name, "conv_b3ks_kernel<%d,%d>", WN, MODE);
+  if (NW == 4) snprintf(name, sizeof name, "conv_b3ks_kernel<%d,%d>", WN, MODE);
+  else snprintf(name, sizeof name, "conv_b3ks_kernel<%d,%d,%d>", WN, MODE, NW);
   return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
-    hipLaunchKernelGGL((conv_b3ks_kernel<WN, MODE>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_b3ks_kernel<WN, MODE, NW>), grid, dim3(64 * NW), lds, stream, a);
   });
 }
 
 // Split-K is for launches whose one-role grid would leave most CUs with a single long reduction chain: few output
 // tiles (at most two blocks per CU) and at least four channel chunks to share out.  Returns false when it does not apply.
+// VITS_CONV_KS8=0 keeps the deepest reductions on four waves (for A/B measurements).
+static bool ks8_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_CONV_KS8");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 template <int MODE>
 static bool try_launch_ks(ConvArgs& a, hipStream_t stream, hipError_t& err) {
   if (!ks_enabled() || a.M % 64 != 0 || a.Cin < 64 || a.in_cbias) return false;
@@ -1602,6 +1622,12 @@ static bool try_launch_ks(ConvArgs& a, hipStream_t stream, hipError_t& err) {
   }
   // beyond two blocks per CU the one-role kernel wins, except for deep reductions (>= 256 channels, >= 5 taps)
   if (best_blocks > 2LL * cus && !(a.Cin >= 256 && a.K >= 5)) return false;
+  // eight waves when the chip is nearly empty and the reduction is deep: at most one block for every fourth CU, >= 32 chunks
+  if (wn == 1 && a.Cin >= 512 && best_blocks * 4 <= cus && (size_t)8 * 6 * (32 + a.width) * sizeof(uint4) <= 64 * 1024 &&
+      ks8_enabled()) {
+    err = launch_b3ks<1, MODE, 8>(a, stream);
+    return true;
+  }
   err = wn == 1 ? launch_b3ks<1, MODE>(a, stream) : wn == 2 ? launch_b3ks<2, MODE>(a, stream) : launch_b3ks<3, MODE>(a, stream);
   return true;
 }
