@@ -1294,7 +1294,7 @@ static hipError_t launch_h2(ConvArgs& a, hipStream_t stream) {
   dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
   const size_t lds = (size_t)4 * a.rs * sizeof(uint4);
   char name[96];
-  if constexpr (MODE == MODE_PLAIN && WM == 2 && WN == 2) {
+  if constexpr (MODE == MODE_PLAIN && WM == 2 && (WN == 2 || (WN == 1 && WGM == 2))) {
     // a grid of at most two blocks per CU is a set of serial chains: the weight-ring variant
     if ((long long)grid.x * grid.y * grid.z <= (long long)f16x2_ring_blocks_per_cu() * device_cu_count()) {
       const bool stg = a.flags & F_IN_STAGED;
@@ -1643,6 +1643,16 @@ static hipError_t launch_cfg(ConvArgs& a, int prec, hipStream_t stream) {
   return launch_f32<WM, WN, WGM, WGN, MODE, false>(a, stream);
 }
 
+// VITS_CONV_SMALL128: the largest grid, in quarter blocks per CU, that gets 128 x 64 tiles in place of the tall or
+// wide ones (default 4 = one block per CU; 0: never).
+static int small128_limit() {
+  static const int n = [] {
+    const char* e = getenv("VITS_CONV_SMALL128");
+    return e && e[0] ? atoi(e) : 4;
+  }();
+  return n;
+}
+
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   if (d.Cin % 16 != 0 || d.M % 32 != 0 || d.K < 1 || d.K > MAX_TAPS) return hipErrorInvalidValue;
   if (d.max_off - d.min_off > MAX_HALO) return hipErrorInvalidValue;
@@ -1676,6 +1686,10 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
     case MODE_PLAIN:
       if (M % 64 == 0) {
         if (L <= 96 && M % 128 == 0) return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, p, stream);
+        // a grid that leaves most CUs empty (batch 1): 128 x 64 tiles, twice the blocks, half the chain
+        if (p == PREC_F16X2 && M % 128 == 0 && small128_limit() > 0 &&
+            (long long)((L + 63) / 64) * (M / 128) * a.B * 4 <= (long long)small128_limit() * device_cu_count())
+          return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, p, stream);
         // taller block tiles when there are enough rows: one staged activation tile then feeds 128 / 256 rows
         if (M % 256 == 0) return launch_cfg<2, 2, 4, 1, MODE_PLAIN>(a, p, stream);
         if (M % 128 == 0) return launch_cfg<2, 2, 2, 2, MODE_PLAIN>(a, p, stream);
