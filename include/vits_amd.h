@@ -46,7 +46,20 @@ const char* vits_version(void);
 
 /* ---- model set-up (replaces module construction + utils.load_checkpoint, reference utils.py:19-49) ---- */
 int vits_model_create(const vits_config* cfg, vits_model** out);
+/* Releases a handle vits_model_create returned.  A pointer that is not a live handle (destroyed before, or never
+ * created by this library) is left alone: nothing is freed and vits_last_error() says so. */
 void vits_model_destroy(vits_model* m);
+/* 1 if m is a live handle of this library, else 0.  Every entry point that takes a model checks this first. */
+int vits_model_alive(const vits_model* m);
+/* How many HIP streams vits_generator may use for this model: the caller's, plus n_streams - 1 of the library's own
+ * (the generator's independent ResBlock chains, reference models.py:292-298, run side by side on them).  Default:
+ * one per ResBlock kernel size.  A caller that drives further streams of its own lowers it to stay within the
+ * process's hardware queues (4 by default).  No counterpart in the reference. */
+int vits_model_set_generator_streams(vits_model* m, int n_streams);
+/* Register a device int32 (zeroed by the caller) that the f16x2 kernels OR 1 into whenever they clamp an activation
+ * to the fp16 range (+-65504) during vits_generator; NULL switches reporting off.  No counterpart in the reference
+ * (its fp32 convs have no such range). */
+int vits_model_set_range_flag(vits_model* m, int* dev_flag);
 /* Register a plain fp32 tensor (bias, LayerNorm gain, embedding table ...) under `name`. The memory stays owned
  * by the caller and must outlive the model. */
 int vits_model_set_tensor(vits_model* m, const char* name, const float* dev_ptr, int64_t numel);
@@ -160,6 +173,9 @@ int vits_profile_read_bytes(int index, double* bytes);
  * conv (leaky-relu(in_slope) applied, converted; plain convs in precision 2 / 3 only), 512 the input is in that format.
  * Staged format, per batch row: 16-byte units of eight channels of one time step, precision 2: bf16 [C/8][L][8];
  * precision 3: fp16 [C/8][L][2 planes h, l][8]. */
+/* Device int32 the f16x2 single operators below OR 1 into when they clamp an activation to the fp16 range (thread-local
+ * setting; NULL, the default, switches it off). */
+void vits_op_set_range_flag(int* dev_flag);
 int vits_op_conv1d(const void* packed_w, const float* bias_rows, int cin, int rows, int taps, int dilation, int mode,
                    int precision, const float* x, int B, int L, const int* lengths, const float* cbias,
                    const float* in_cbias, const float* res, float* out, int flags, float in_scale, float in_slope,

@@ -257,3 +257,166 @@ def test_infer_at_the_length_limits(gpu_model, oracle_model):
     # the model still works after the refused call
     again = gpu_model.infer(b.phonemes, b.lengths, **kw)[0]
     assert torch.equal(again, o)
+
+
+def _model(synthetic_sd, precision=None, cfg=None, **kw):
+    from vits_amd import SynthesizerTrn
+    cfg = cfg or synthetic.ModelConfig()
+    net = SynthesizerTrn(cfg.n_vocab, cfg.spec_channels, cfg.hop_length, cfg.sampling_rate, cfg.segment_size,
+                         precision=precision, **cfg.kwargs(), **kw).eval()
+    net.load_state_dict(synthetic_sd)
+    return net
+
+
+def test_infer_c3_bf16_fullsize_properties(synthetic_sd, gpu_model):
+    """BASELINE configs[2] as quoted: 64 utterances x 861 frames (160 phonemes) with bf16 generator convs.  Too large
+    for the CPU oracle, so: same inputs => same bytes; latents (everything upstream of the generator stays
+    fp32-grade) equal to the default mode's; waveform inside the bf16 envelope (BF16_WAV_TOL / BF16_MEL_TOL, the
+    tolerances test_infer_bf16_generator_mode pins against the reference goldens) of the fp32-grade waveform of the
+    same batch; a row inside the same envelope of its own batch-1 result (equal lengths => no padding)."""
+    net = _model(synthetic_sd, "bf16")
+    b = synthetic.config_c3()
+    kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
+    o, x_mask, (z, *_), *_ = net.infer(b.phonemes, b.lengths, **kw)
+    assert o.shape == (64, 1, 861 * 512) and bool(x_mask.all())
+    assert torch.isfinite(o).all() and float(o.abs().max()) <= 1.0
+    o2 = net.infer(b.phonemes, b.lengths, **kw)[0]
+    assert torch.equal(o, o2)
+    del o2
+    ref, _, (z_ref, *_), *_ = gpu_model.infer(b.phonemes, b.lengths, **kw)          # f16x2: fp32-grade
+    assert metrics.max_abs(z, z_ref) <= 1e-5
+    assert metrics.max_abs(o, ref) <= BF16_WAV_TOL
+    for i in (0, 41):
+        assert metrics.log_mel_l1(o[i], ref[i]) <= BF16_MEL_TOL
+    del ref
+    i = 29
+    o1 = net.infer(b.phonemes[i:i + 1], b.lengths[i:i + 1], sid=b.sid[i:i + 1], noise=b.noise[i:i + 1],
+                   noise_scale=b.noise_scale, duration_control=b.durations[i:i + 1])[0]
+    assert metrics.max_abs(o1[0], o[i]) <= BF16_WAV_TOL
+    assert not net.range_overflow() and not gpu_model.range_overflow()
+
+
+def test_infer_c4_corpus_slice(gpu_model, oracle_model):
+    """BASELINE configs[3] (the 10 000-utterance corpus: lognormal lengths clipped to 88..1400 frames, sorted, cut
+    into batches of <= 64): a fixed slice of its batches -- the longest, the shortest, the first ragged one and a
+    ragged one from the middle -- through infer_batches, the path the corpus benchmark uses.
+      * every batch: the bytes plain infer() returns for it (throughput mode changes nothing), masks = frame counts;
+      * the small ragged batch: the whole batch, padded tails included, against the CPU oracle (parity is defined per
+        identical batch: padding leaks into valid positions, reference models.py:746-765);
+      * the unpadded batches: a row equals its own batch-1 result, and that one against the oracle."""
+    batches = synthetic.corpus_c4(10000)
+    assert len(batches) == 157 and batches[0][1][0] == 88 and batches[-1][1][-1] == 1400
+    ragged = next(i for i, (_, ts) in enumerate(batches) if len(set(ts)) > 1)
+    picks = [155, 0, ragged, 78]                       # 155: the heaviest batch, 64 utterances of 1400 frames
+    assert batches[155][1] == [1400] * 64
+    assert len(set(batches[78][1])) > 1
+    data = [synthetic.make_batch(1000 + i, *batches[i]) for i in picks]
+    kws = [dict(phonemes=b.phonemes, phonemes_lengths=b.lengths, sid=b.sid, noise_scale=b.noise_scale,
+                duration_control=b.durations, noise=b.noise) for b in data]
+    got = list(gpu_model.infer_batches(kws))
+    assert len(got) == len(picks)
+    for b, kw, g in zip(data, kws, got):
+        k = dict(kw)
+        r = gpu_model.infer(k.pop("phonemes"), k.pop("phonemes_lengths"), **k)
+        assert torch.equal(g[0], r[0]) and torch.equal(g[1], r[1]) and torch.equal(g[2][0], r[2][0])
+        assert g[0].shape == (len(b.frames), 1, int(b.frames.max()) * 512)
+        assert torch.isfinite(g[0]).all() and float(g[0].abs().max()) <= 1.0
+        assert torch.equal(g[1].sum(dim=(1, 2)).cpu(), b.frames)
+        del r
+    # the first ragged batch of the corpus, whole, against the oracle
+    b, g = data[2], got[2]
+    ref = oracle_model.infer(b.phonemes, b.lengths, sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations,
+                             noise=b.noise)
+    assert metrics.max_abs(g[0], ref[0]) <= WAV_TOL
+    assert metrics.max_abs(g[2][0], ref[2][0]) <= LATENT_TOL
+    for j in (0, len(b.frames) - 1):
+        n = int(b.frames[j]) * 512
+        assert metrics.log_mel_l1(g[0][j:j + 1, 0, :n], ref[0][j:j + 1, 0, :n]) <= MEL_TOL
+    # unpadded batches (all rows of one length): row independence, then the oracle on that single utterance
+    for bi, row in ((0, 17), (1, 40)):
+        b, g = data[bi], got[bi]
+        assert len(set(b.frames.tolist())) == 1
+        kw1 = dict(sid=b.sid[row:row + 1], noise_scale=b.noise_scale, duration_control=b.durations[row:row + 1],
+                   noise=b.noise[row:row + 1])
+        o1 = gpu_model.infer(b.phonemes[row:row + 1], b.lengths[row:row + 1], **kw1)[0]
+        assert metrics.max_abs(o1[0], g[0][row]) <= 1e-5
+        ref1 = oracle_model.infer(b.phonemes[row:row + 1], b.lengths[row:row + 1], **kw1)[0]
+        assert metrics.max_abs(o1, ref1) <= WAV_TOL
+        assert metrics.log_mel_l1(o1[:, 0], ref1[:, 0]) <= MEL_TOL
+    assert not gpu_model.range_overflow()
+
+
+def test_generator_chain_with_unfusable_pair(synthetic_sd):
+    """A ResBlock whose pairs do not all qualify for the fused-pair kernel (kernel 7 with dilation 9: the first conv's
+    halo of 27 samples is beyond the fused kernel's 25) must still produce the reference's output: the chain is then
+    run unfused as a whole.  Checked against the oracle with the same dilations."""
+    import dataclasses
+    from oracle.mvts_oracle import OracleSynthesizer
+    dil = ((1, 3, 5), (1, 3, 9), (1, 2, 6))
+    cfg = dataclasses.replace(synthetic.ModelConfig(), resblock_dilation_sizes=dil)
+    net = _model(synthetic_sd, cfg=cfg)
+    orc = OracleSynthesizer(synthetic_sd, resblock_dilation_sizes=dil)
+    b = synthetic.make_batch(51, [11, 7], [37, 29])
+    kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
+    o = net.infer(b.phonemes, b.lengths, **kw)[0]
+    ref = orc.infer(b.phonemes, b.lengths, **kw)[0]
+    assert o.shape == ref.shape
+    assert metrics.max_abs(o, ref) <= WAV_TOL
+    assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= MEL_TOL
+
+
+def test_f16x2_range_overflow_is_reported(synthetic_sd):
+    """The default arithmetic (f16x2) clamps activations to the fp16 range.  A checkpoint whose generator leaves that
+    range must be reported: range_overflow() turns true, the next infer warns once and names precision="bf16x3"
+    (or raises with strict_range=True), and bf16x3 runs the same checkpoint without a report."""
+    import warnings
+    sd = dict(synthetic_sd)
+    sd["dec.conv_pre.weight"] = sd["dec.conv_pre.weight"] * 1.0e5        # |weights| stay inside the fp16 range
+    sd["dec.conv_pre.bias"] = sd["dec.conv_pre.bias"] * 1.0e5
+    b = synthetic.make_batch(61, [8], [24])
+    kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
+    net = _model(sd)
+    assert not net.range_overflow()
+    net.infer(b.phonemes, b.lengths, **kw)
+    assert net.range_overflow()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        net.infer(b.phonemes, b.lengths, **kw)
+        net.infer(b.phonemes, b.lengths, **kw)
+    msgs = [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning)]
+    assert len(msgs) == 1 and "bf16x3" in msgs[0] and "65504" in msgs[0]
+    strict = _model(sd, strict_range=True)
+    strict.infer(b.phonemes, b.lengths, **kw)
+    with pytest.raises(OverflowError, match="bf16x3"):
+        strict.infer(b.phonemes, b.lengths, **kw)
+    wide = _model(sd, "bf16x3")
+    wide.infer(b.phonemes, b.lengths, **kw)
+    assert not wide.range_overflow()
+    ok = _model(synthetic_sd)
+    ok.infer(b.phonemes, b.lengths, **kw)
+    assert not ok.range_overflow()
+
+
+def test_model_is_exclusive_and_stream_safe(gpu_model):
+    """One workspace serves every call: a second thread inside a call is refused, and a call issued on another
+    stream than the previous one waits for it instead of overwriting its scratch."""
+    b = synthetic.make_batch(71, [10, 6], [60, 33])
+    kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
+    ref = gpu_model.infer(b.phonemes, b.lengths, **kw)[0]
+    assert gpu_model._busy.acquire(blocking=False)
+    try:
+        with pytest.raises(RuntimeError, match="re-entrant"):
+            gpu_model.infer(b.phonemes, b.lengths, **kw)
+        with pytest.raises(RuntimeError, match="re-entrant"):
+            next(iter(gpu_model.infer_batches([dict(phonemes=b.phonemes, phonemes_lengths=b.lengths, **kw)])))
+    finally:
+        gpu_model._busy.release()
+    side = torch.cuda.Stream()
+    big = synthetic.make_batch(72, [50] * 8, [258] * 8)
+    kwb = dict(sid=big.sid, noise_scale=big.noise_scale, duration_control=big.durations, noise=big.noise)
+    with torch.cuda.stream(side):
+        o_side = gpu_model.infer(big.phonemes, big.lengths, **kwb)[0]          # still running when the next call starts
+    o_main = gpu_model.infer(b.phonemes, b.lengths, **kw)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(o_main, ref)
+    assert torch.equal(o_side, gpu_model.infer(big.phonemes, big.lengths, **kwb)[0])

@@ -183,3 +183,130 @@ def test_generator_halo_frames():
     import dataclasses
     wide = dataclasses.replace(cfg, resblock_kernel_sizes=(3, 7, 13))
     assert generator_halo_frames(wide) > 13
+
+
+def _cpu_model(monkeypatch):
+    """A SynthesizerTrn whose upload step (the only part that needs a GPU) is recorded instead of run."""
+    from vits_amd import SynthesizerTrn
+    cfg = synthetic.ModelConfig()
+    net = SynthesizerTrn(cfg.n_vocab, cfg.spec_channels, cfg.hop_length, cfg.sampling_rate, cfg.segment_size,
+                         **cfg.kwargs()).eval()
+    uploads = []
+    monkeypatch.setattr(net, "_upload", lambda pw=None: uploads.append(len(net._sd)))
+    return net, uploads
+
+
+def test_load_checkpoint_end_to_end(tmp_path, monkeypatch, synthetic_sd, capsys):
+    """utils.load_checkpoint on a file written the way the reference writes it (reference utils.py:52-68:
+    {'model', 'iteration', 'optimizer', 'learning_rate'}) and its tolerant key-by-key behaviour (utils.py:19-49):
+    keys the file lacks or holds with another shape are reported and left to the model, which accepts that for
+    tensors infer never reads and refuses it for tensors it needs."""
+    net, uploads = _cpu_model(monkeypatch)
+    path = str(tmp_path / "G_1000.pth")
+    torch.save({"model": dict(synthetic_sd), "iteration": 1000, "optimizer": {"state": {}, "param_groups": []},
+                "learning_rate": 2e-4}, path)
+    model, opt, lr, it = utils.load_checkpoint(path, net, None)
+    assert model is net and opt is None and lr == 2e-4 and it == 1000
+    assert uploads == [len(synthetic_sd)] and set(net._sd) == set(synthetic_sd)
+    assert torch.equal(net._sd["dec.conv_post.weight"], synthetic_sd["dec.conv_post.weight"])
+    assert "is not in the checkpoint" not in capsys.readouterr().out
+
+    # optional keys absent (enc_q.*, enc_p.proj.*: present in reference checkpoints, never read by infer)
+    optional = {k for k in synthetic_sd if k.startswith(weights.UNUSED_PREFIXES)}
+    assert optional and any(k.startswith("enc_q.") for k in optional)
+    torch.save({"model": {k: v for k, v in synthetic_sd.items() if k not in optional}, "iteration": 7,
+                "learning_rate": 1e-4}, path)
+    fresh, _ = _cpu_model(monkeypatch)
+    _, _, lr, it = utils.load_checkpoint(path, fresh, None)
+    assert (lr, it) == (1e-4, 7) and set(fresh._sd) == set(synthetic_sd) - optional
+    # a model that already holds a value keeps it, as the reference's module keeps its current parameter
+    utils.load_checkpoint(path, net, None)
+    assert set(net._sd) == set(synthetic_sd)
+    out = capsys.readouterr().out
+    assert f"error, {sorted(optional)[0]} is not in the checkpoint" in out
+
+    # a required key absent: reported like the reference does, then refused (an uninitialised weight is not audio)
+    torch.save({"model": {k: v for k, v in synthetic_sd.items() if k != "dec.conv_pre.weight"}, "iteration": 1,
+                "learning_rate": 0.0}, path)
+    with pytest.raises(RuntimeError, match="dec.conv_pre.weight"):
+        utils.load_checkpoint(path, _cpu_model(monkeypatch)[0], None)
+    assert "error, dec.conv_pre.weight is not in the checkpoint" in capsys.readouterr().out
+
+    # a mis-shaped key is treated like an absent one (the reference's bare except, utils.py:38-41)
+    bad = dict(synthetic_sd)
+    bad["emb_g.weight"] = torch.zeros(3, 5)
+    torch.save({"model": bad, "iteration": 1, "learning_rate": 0.0}, path)
+    with pytest.raises(RuntimeError, match="emb_g.weight"):
+        utils.load_checkpoint(path, _cpu_model(monkeypatch)[0], None)
+    assert "error, emb_g.weight is not in the checkpoint" in capsys.readouterr().out
+    bad = dict(synthetic_sd)
+    bad["enc_p.proj.weight"] = torch.zeros(3, 5)          # optional and mis-shaped: reported, load goes through
+    torch.save({"model": bad, "iteration": 2, "learning_rate": 0.0}, path)
+    fresh, _ = _cpu_model(monkeypatch)
+    assert utils.load_checkpoint(path, fresh, None)[3] == 2
+    assert "enc_p.proj.weight" not in fresh._sd
+
+    # a bare state dict (no 'model' wrapper) loads too
+    torch.save(dict(synthetic_sd), path)
+    assert utils.load_checkpoint(path, net, None)[2:] == (0.0, 0)
+
+
+def test_model_handles_are_checked():
+    """The C ABI hands out raw pointers: destroying one twice, destroying a pointer the library never made, or
+    calling an entry point with either must be an error, not a double free."""
+    import ctypes as C
+    cfg = synthetic.ModelConfig()
+    from vits_amd import SynthesizerTrn
+    net = SynthesizerTrn(cfg.n_vocab, cfg.spec_channels, cfg.hop_length, cfg.sampling_rate, cfg.segment_size,
+                         **cfg.kwargs())
+    h = C.c_void_p(net._handle.value)
+    assert N.lib.vits_model_alive(h) == 1
+    N.lib.vits_model_destroy(h)
+    assert N.lib.vits_model_alive(h) == 0
+    N.lib.vits_model_destroy(h)                                   # second destroy of the same pointer: ignored
+    assert b"not a live model handle" in N.lib.vits_last_error()
+    assert N.lib.vits_model_finalize(h) == -1 and N.lib.vits_cond_rows(h) == -1
+    assert N.lib.vits_encoder_workspace_bytes(h, 1, 8) == -1
+    junk = C.create_string_buffer(4096)                           # a pointer the library never created
+    N.lib.vits_model_destroy(C.cast(junk, C.c_void_p))
+    assert N.lib.vits_model_alive(C.cast(junk, C.c_void_p)) == 0
+    del net                                                       # __del__ destroys again: must be harmless
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` started plainly launches N children with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set (the reference's train.py:44-48 spawns its workers itself, too), and a rank refuses to report a
+    GPU count other than --gpus."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None):
+            started.append((cmd, env, stdout))
+
+        def poll(self):
+            return 0
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--backend", "gloo"])
+    assert bench.spawn_ranks(argparse.Namespace(gpus=4, backend="gloo")) == 0
+    assert len(started) == 4
+    ports = {env["MASTER_PORT"] for _, env, _ in started}
+    assert len(ports) == 1
+    for r, (cmd, env, stdout) in enumerate(started):
+        assert cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--backend", "gloo"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"]) == (str(r), str(r), "4", "127.0.0.1")
+        assert (stdout is None) == (r == 0)                       # rank 0 prints the JSON line
+    # more ranks than GPUs over RCCL is refused before anything starts (no GPU in this container: count is 0)
+    if torch.cuda.device_count() < 2:
+        with pytest.raises(SystemExit):
+            bench.spawn_ranks(argparse.Namespace(gpus=2, backend="nccl"))
+    # a rank whose WORLD_SIZE disagrees with --gpus stops instead of printing a line with the wrong n_gpus
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit, match="WORLD_SIZE"):
+        bench.main()

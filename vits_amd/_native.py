@@ -45,6 +45,9 @@ def _load():
         "vits_version": (C.c_char_p, []),
         "vits_model_create": (i32, [C.POINTER(VitsConfig), C.POINTER(vp)]),
         "vits_model_destroy": (None, [vp]),
+        "vits_model_alive": (i32, [vp]),
+        "vits_model_set_generator_streams": (i32, [vp, i32]),
+        "vits_model_set_range_flag": (i32, [vp, vp]),
         "vits_model_set_tensor": (i32, [vp, C.c_char_p, vp, i64]),
         "vits_model_set_conv": (i32, [vp, C.c_char_p, vp, vp, i32, i32, i32, i32, i32, i32]),
         "vits_model_finalize": (i32, [vp]),
@@ -76,6 +79,7 @@ def _load():
         "vits_profile_read_bytes": (i32, [i32, C.POINTER(C.c_double)]),
         "vits_profile_read": (i32, [i32, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int64)]),
+        "vits_op_set_range_flag": (None, [vp]),
         "vits_op_conv1d": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, f32, f32, vp]),
         "vits_op_resblock_pair": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, C.c_float, vp]),
         "vits_op_layer_norm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

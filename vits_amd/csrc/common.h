@@ -75,6 +75,8 @@ struct ConvArgs {
   float in_scale, in_slope;
   float out_slope;                                   // F_OUT_STAGED: leaky-relu slope the consumer would apply
   int toff0[2], tstep[2];                            // tap k reads x[t + toff0 + k * tstep] (per row class)
+  int* range_flag;                                   // PREC_F16X2: OR 1 into *range_flag when an activation lies outside
+                                                     // the fp16 range and was clamped (null: not reported)
 };
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
@@ -87,6 +89,7 @@ struct PairArgs {
   int B, L;
   int accumulate;                // out += result (read-modify-write)
   float slope;                   // leaky-relu slope before both convs
+  int* range_flag = nullptr;     // OR 1 into it when an activation was clamped to the fp16 range (null: not reported)
 };
 bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2);       // the kernel supports the shape (32 or 64 channels)
 bool pair_profitable(const ConvDesc& c1, const ConvDesc& c2);    // ... and is the faster choice for it

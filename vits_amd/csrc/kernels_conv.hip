@@ -667,6 +667,12 @@ struct IntC { static constexpr int value = V; };
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// f16x2 operands are clamped to the fp16 range at conversion; a caller that wants to know passes a device word, and
+// every thread that clamped a value ORs 1 into it (a not-taken branch otherwise).
+__device__ __forceinline__ void report_f16_range(int* flag, float amax) {
+  if (flag && !(amax <= 65504.f)) atomicOr(flag, 1);
+}
+
 // Epilogue for F_OUT_STAGED (MODE_PLAIN): result + bias (+ conditioning bias) -> leaky-relu(out_slope) -> the consumer's
 // operand format.  A lane holds, per 8-row group g of an m-tile, the four channels 8g + 4*par .. + 3 of its time step:
 // half of a 16-byte unit, so one 8-byte store per group (and per plane).  PLANES = 1: bf16; PLANES = 2: fp16 h / l split.
@@ -707,6 +713,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x16 (
           out_b[unit * 2 + par] = o;
         } else {
           uint2 oh, ol;
+          report_f16_range(a.range_flag, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             f32x2 e = {fminf(fmaxf(v[2 * u], -65504.f), 65504.f), fminf(fmaxf(v[2 * u + 1], -65504.f), 65504.f)};
@@ -1010,6 +1017,7 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
         bool ok = t >= 0 && t < a.L;
         if (a.flags & F_IN_MASK) ok = ok && t < len_b;
         unsigned ph[8], pl[8];
+        float amax = 0.f;                               // largest magnitude of the column's 16 values, before the clamp
 #pragma unroll
         for (int c2 = 0; c2 < 8; ++c2) {
           f32x2 v;
@@ -1018,6 +1026,7 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
             const int ci = 2 * c2 + u;
             float e = (st[q][ci] + (cbp ? cbp[ci] : 0.f)) * a.in_scale;
             if (a.flags & F_IN_LRELU) e = fmaxf(e, e * a.in_slope);
+            amax = fmaxf(amax, fabsf(e));
             e = fminf(fmaxf(e, -65504.f), 65504.f);
             v[u] = ok ? e : 0.f;
           }
@@ -1027,6 +1036,7 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
           ph[c2] = __builtin_bit_cast(unsigned, h);
           pl[c2] = __builtin_bit_cast(unsigned, l);
         }
+        report_f16_range(a.range_flag, amax);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           xq[(0 * 2 + hf) * ncols + col] = make_uint4(ph[4 * hf], ph[4 * hf + 1], ph[4 * hf + 2], ph[4 * hf + 3]);
@@ -1776,6 +1786,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
       if (col < ncols) {
         const bool ok = t >= 0 && t < a.L;
         unsigned ph[8], pl[8];
+        float amax = 0.f;
 #pragma unroll
         for (int c2 = 0; c2 < 8; ++c2) {
           f32x2 v;
@@ -1783,6 +1794,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
           for (int u = 0; u < 2; ++u) {
             float e = st[q][2 * c2 + u];
             e = fmaxf(e, e * a.slope);
+            amax = fmaxf(amax, fabsf(e));
             e = fminf(fmaxf(e, -65504.f), 65504.f);
             v[u] = ok ? e : 0.f;
           }
@@ -1791,6 +1803,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
           ph[c2] = __builtin_bit_cast(unsigned, h);
           pl[c2] = __builtin_bit_cast(unsigned, l);
         }
+        report_f16_range(a.range_flag, amax);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           xq[(0 * 2 + hf) * ncols + col] = make_uint4(ph[4 * hf], ph[4 * hf + 1], ph[4 * hf + 2], ph[4 * hf + 3]);
@@ -1880,7 +1893,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
   // ---- Y = split(lrelu(c1 + bias)), zero outside the sequence; 8-byte pieces (four channels of a half) ----
   {
     uint2* y2 = reinterpret_cast<uint2*>(yq);
-    float bz[16];
+    float bz[16], ymax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bz[r] = b1 ? b1[32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
 #pragma unroll
@@ -1898,6 +1911,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
           for (int q = 0; q < 2; ++q) {
             float v = acc[j][4 * g + 2 * u + q] + bz[4 * g + 2 * u + q];
             v = fmaxf(v, v * a.slope);
+            ymax = fmaxf(ymax, fabsf(v));
             v = fminf(fmaxf(v, -65504.f), 65504.f);
             e[q] = inside ? v : 0.f;
           }
@@ -1911,6 +1925,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
         y2[(((chunk2 * 2 + 1) * 2 + half) * W1 + c) * 2 + par] = ol;
       }
     }
+    report_f16_range(a.range_flag, ymax);
   }
   __syncthreads();
   // ---- second conv on the inner BN steps ----

@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,27 @@ int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+
+// Every handle vits_model_create has returned and vits_model_destroy has not yet released.  The C ABI hands out raw
+// pointers; a caller that destroys one twice, or passes a pointer the library never made (a copied or stale handle),
+// must get an error, not a double free.
+std::mutex g_models_mu;
+std::set<const vits_model*> g_models;
+
+bool model_alive(const vits_model* m) {
+  if (!m) return false;
+  std::lock_guard<std::mutex> lk(g_models_mu);
+  return g_models.count(m) != 0;
+}
+
+// Device word the f16x2 kernels OR 1 into when an activation leaves the fp16 range (set per entry-point call from the
+// model; read by conv_simple and the pair launcher on the same host thread).
+thread_local int* g_range_flag = nullptr;
+struct RangeFlagScope {
+  int* prev;
+  explicit RangeFlagScope(int* f) : prev(g_range_flag) { g_range_flag = f; }
+  ~RangeFlagScope() { g_range_flag = prev; }
+};
 
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
@@ -80,6 +103,8 @@ struct vits_model {
   hipStream_t side[8] = {};
   hipEvent_t ev_fork = nullptr, ev_done[8] = {};
   int n_side = 0;
+  int side_limit = 8;                // vits_model_set_generator_streams: how many of them vits_generator may use
+  int* range_flag = nullptr;         // vits_model_set_range_flag
 };
 
 namespace {
@@ -174,6 +199,7 @@ int conv_simple(const ConvDesc& d, const float* x, float* out, int B, int L, con
   a.cbias = cbias; a.cbias_bs = cbias_bs;
   a.in_cbias = in_cbias; a.in_cbias_bs = in_cbias_bs;
   a.in_scale = in_scale; a.in_slope = in_slope;
+  a.range_flag = g_range_flag;
   HIP_TRY(launch_conv(d, a, s));
   return VITS_OK;
 }
@@ -242,7 +268,9 @@ ConvDesc need_conv(vits_model* m, const std::string& name, int cin, int rows, in
 extern "C" {
 
 const char* vits_last_error(void) { return g_err.c_str(); }
-const char* vits_version(void) { return "vits_amd 0.1 (gfx950, fp32 MFMA)"; }
+const char* vits_version(void) {
+  return "vits_amd 0.2 (gfx950; MFMA convs: f16x2 / bf16x3 / fp32 / bf16, fp32 accumulate)";
+}
 
 int vits_model_create(const vits_config* cfg, vits_model** out) {
   if (!cfg || !out) return fail(VITS_ERR_INVALID, "null argument");
@@ -266,6 +294,10 @@ int vits_model_create(const vits_config* cfg, vits_model** out) {
   }
   vits_model* m = new vits_model();
   m->cfg = c;
+  {
+    std::lock_guard<std::mutex> lk(g_models_mu);
+    g_models.insert(m);
+  }
   *out = m;
   return VITS_OK;
 }
@@ -283,12 +315,36 @@ static void release_streams(vits_model* m) {
 
 void vits_model_destroy(vits_model* m) {
   if (!m) return;
+  {
+    // only a live handle of this library is released: a second destroy of the same pointer, or a pointer that
+    // vits_model_create never returned, is ignored (and reported through vits_last_error)
+    std::lock_guard<std::mutex> lk(g_models_mu);
+    if (g_models.erase(m) == 0) {
+      g_err = "vits_model_destroy: not a live model handle (already destroyed, or not created by this library)";
+      return;
+    }
+  }
   release_streams(m);
   delete m;
 }
 
+int vits_model_alive(const vits_model* m) { return model_alive(m) ? 1 : 0; }
+
+int vits_model_set_generator_streams(vits_model* m, int n_streams) {
+  if (!model_alive(m)) return fail(VITS_ERR_INVALID, "set_generator_streams: not a live model handle");
+  if (n_streams < 1) return fail(VITS_ERR_INVALID, "set_generator_streams: at least the caller's stream");
+  m->side_limit = n_streams - 1;
+  return VITS_OK;
+}
+
+int vits_model_set_range_flag(vits_model* m, int* dev_flag) {
+  if (!model_alive(m)) return fail(VITS_ERR_INVALID, "set_range_flag: not a live model handle");
+  m->range_flag = dev_flag;
+  return VITS_OK;
+}
+
 int vits_model_set_tensor(vits_model* m, const char* name, const float* p, int64_t numel) {
-  if (!m || !name || !p || numel <= 0) return fail(VITS_ERR_INVALID, "set_tensor: bad argument");
+  if (!model_alive(m) || !name || !p || numel <= 0) return fail(VITS_ERR_INVALID, "set_tensor: bad argument");
   m->plain[name] = Plain{p, numel};
   m->finalized = false;
   return VITS_OK;
@@ -296,7 +352,7 @@ int vits_model_set_tensor(vits_model* m, const char* name, const float* p, int64
 
 int vits_model_set_conv(vits_model* m, const char* name, const void* w, const float* bias, int cin, int rows, int taps,
                         int dilation, int mode, int precision) {
-  if (!m || !name || !w) return fail(VITS_ERR_INVALID, "set_conv: bad argument");
+  if (!model_alive(m) || !name || !w) return fail(VITS_ERR_INVALID, "set_conv: bad argument");
   ConvDesc d;
   TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode, precision));
   m->convs[name] = d;
@@ -305,7 +361,7 @@ int vits_model_set_conv(vits_model* m, const char* name, const void* w, const fl
 }
 
 int vits_model_finalize(vits_model* m) {
-  if (!m) return fail(VITS_ERR_INVALID, "null model");
+  if (!model_alive(m)) return fail(VITS_ERR_INVALID, "finalize: not a live model handle");
   const vits_config& c = m->cfg;
   const int C = c.hidden_channels, F = c.filter_channels, G = c.gin_channels, half = c.inter_channels / 2;
   const int NR = 2 * c.window_size + 1, DK = C / c.n_heads;
@@ -522,10 +578,11 @@ int vits_pack_conv_weight_f16x2(const float* w, int rows, int cin, int taps, uin
   return VITS_OK;
 }
 
-#define CHECK_MODEL(m)                                                             \
-  if (!(m) || !(m)->finalized) return fail(VITS_ERR_INVALID, "model not finalized")
+#define CHECK_MODEL(m)                                                                                  \
+  if (!model_alive(m)) return fail(VITS_ERR_INVALID, "not a live model handle");                        \
+  if (!(m)->finalized) return fail(VITS_ERR_INVALID, "model not finalized")
 
-int vits_cond_rows(const vits_model* m) { return m && m->finalized ? m->cond_rows : -1; }
+int vits_cond_rows(const vits_model* m) { return model_alive(m) && m->finalized ? m->cond_rows : -1; }
 
 int vits_speaker_cond(const vits_model* m, const int64_t* sid, int B, float* cond, int* err_flag, void* stream) {
   CHECK_MODEL(m);
@@ -535,7 +592,7 @@ int vits_speaker_cond(const vits_model* m, const int64_t* sid, int B, float* con
 }
 
 int64_t vits_encoder_workspace_bytes(const vits_model* m, int B, int L) {
-  if (!m) return -1;
+  if (!model_alive(m)) return -1;
   return encoder_ws_floats(m, B, L) * 4;
 }
 
@@ -557,7 +614,7 @@ int vits_encoder_stack(const vits_model* m, int which, float* x, const int* leng
 }
 
 int64_t vits_variance_workspace_bytes(const vits_model* m, int B, int P) {
-  if (!m) return -1;
+  if (!model_alive(m)) return -1;
   const int64_t C = m->cfg.hidden_channels, EF = m->cfg.energy_filter, DF = m->cfg.dur_filter;
   const int64_t big = std::max<int64_t>(std::max<int64_t>(EF, DF), C);
   return 2 * pad256((int64_t)B * big * P) + 6 * pad256((int64_t)B * P) + encoder_ws_floats(m, B, P) * 4;
@@ -646,7 +703,7 @@ int vits_frame_prior(const vits_model* m, float* x_frame, const int* frame_lengt
 }
 
 int64_t vits_flow_workspace_bytes(const vits_model* m, int B, int T) {
-  if (!m) return -1;
+  if (!model_alive(m)) return -1;
   return 3 * pad256((int64_t)B * m->cfg.hidden_channels * T);
 }
 
@@ -710,16 +767,20 @@ int vits_flow_reverse(const vits_model* m, float* z, const int* lengths, const f
   return run_flow(m, z, lengths, cond, B, T, ws, ws_bytes, (hipStream_t)stream, true);
 }
 
+void vits_op_set_range_flag(int* dev_flag) { g_range_flag = dev_flag; }
+
 int vits_flow_forward(const vits_model* m, float* z, const int* lengths, const float* cond, int B, int T, void* ws,
                       int64_t ws_bytes, void* stream) {
   CHECK_MODEL(m);
   return run_flow(m, z, lengths, cond, B, T, ws, ws_bytes, (hipStream_t)stream, false);
 }
 
-int vits_posterior_channels(const vits_model* m) { return m && m->finalized && m->has_encq ? m->encq_cin : -1; }
+int vits_posterior_channels(const vits_model* m) {
+  return model_alive(m) && m->finalized && m->has_encq ? m->encq_cin : -1;
+}
 
 int64_t vits_posterior_workspace_bytes(const vits_model* m, int B, int T) {
-  if (!m) return -1;
+  if (!model_alive(m)) return -1;
   return 3 * pad256((int64_t)B * m->cfg.hidden_channels * T);
 }
 
@@ -772,7 +833,7 @@ static bool fused_pairs_enabled() {
 }
 
 int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec) {
-  if (!m) return -1;
+  if (!model_alive(m)) return -1;
   return (2 + 2 * (int64_t)m->cfg.n_resblock_kernels) * pad256(gen_buf_floats(m, B, t_dec));
 }
 
@@ -793,11 +854,13 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
   }
   if (!X || !XS) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
   // per-kernel event timing needs the launches of one step serialised on one stream
-  const int n_side = prof_enabled() ? 0 : m->n_side;
+  const int n_side = prof_enabled() ? 0 : std::max(0, std::min(m->n_side, m->side_limit));
+  RangeFlagScope range_scope(m->range_flag);
   // conv_pre on (z * mask)[:, :, :t_dec] + cond(g)   (reference models.py:285-287, 765)
   {
     ConvArgs a = base_args(z, (long long)IC * T, T, XS, (long long)ch0 * t_dec, t_dec, B, t_dec, lengths, F_IN_MASK);
     a.cbias = cond + m->off_dec; a.cbias_bs = m->cond_rows;
+    a.range_flag = g_range_flag;
     HIP_TRY(launch_conv(m->conv_pre, a, s));
   }
   float in_scale = 1.f;
@@ -817,10 +880,16 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
       hipStream_t sj = (j == 0 || n_side == 0) ? s : m->side[std::min(j, n_side) - 1];
       const ResBlock& rb = m->rbs[i * nk + j];
       const float* yin = X;
+      // One decision per chain: the fused pair ping-pongs between Y and T (its blocks read a halo of their input, so
+      // it cannot run in place) while the two-launch pair keeps T for the tensor between its convs and updates Y in
+      // place; a chain that mixed the two would hand a fused pair's output in T to a two-launch pair that overwrites
+      // T before reading it.  So a chain is fused only when every one of its pairs is.
+      bool fuse_chain = fused_pairs_enabled();
+      for (int q = 0; q < nd && fuse_chain; ++q) fuse_chain = pair_profitable(rb.c1[q], rb.c2[q]);
       for (int q = 0; q < nd; ++q) {
-        if (fused_pairs_enabled() && pair_profitable(rb.c1[q], rb.c2[q])) {
-          // 32-channel stage: the whole pair in one launch, the tensor between the convs never leaves LDS.  Blocks
-          // read a halo of their input, so the pair cannot run in place: Y and T take turns as the chain's carrier.
+        if (fuse_chain) {
+          // the whole pair in one launch, the tensor between the convs never leaves LDS; Y and T take turns as the
+          // chain's carrier
           const bool last = q + 1 == nd;
           float* dst = last ? XS : ((q & 1) ? Tt[j] : Y[j]);
           if (last && j > 0 && n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
@@ -828,6 +897,7 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
           pa.x = yin; pa.x_bs = (long long)rb.c1[q].Cin * L; pa.x_cs = L;
           pa.out = dst; pa.out_bs = (long long)rb.c1[q].Cin * L; pa.out_cs = L;
           pa.B = B; pa.L = L; pa.accumulate = last && j > 0; pa.slope = 0.1f;
+          pa.range_flag = g_range_flag;
           HIP_TRY(launch_resblock_pair(rb.c1[q], rb.c2[q], pa, sj));
           yin = dst;
           continue;
@@ -903,6 +973,7 @@ int vits_op_resblock_pair(const void* w1, const float* b1, const void* w2, const
   pa.x = x; pa.x_bs = (long long)channels * L; pa.x_cs = L;
   pa.out = out; pa.out_bs = (long long)channels * L; pa.out_cs = L;
   pa.B = B; pa.L = L; pa.accumulate = accumulate; pa.slope = slope;
+  pa.range_flag = g_range_flag;
   HIP_TRY(launch_resblock_pair(c1, c2, pa, (hipStream_t)stream));
   return VITS_OK;
 }

@@ -8,8 +8,11 @@ GPU this module raises.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
+import threading
+import warnings
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -63,6 +66,15 @@ class SynthesizerTrn:
         self._ws: Optional[torch.Tensor] = None
         self._ready = False
         self.device = torch.device("cuda", 0)
+        # One workspace and one set of generator fork / join events serve every call, so the model is neither
+        # re-entrant nor multi-stream: a second thread inside a call gets a RuntimeError (the reference's server
+        # serialises requests the same way, inference_api.py:13,40), and a call on another stream than the previous
+        # one first waits for the previous call's work (_busy / _last_use below).
+        self._busy = threading.Lock()
+        self._last_use = None                # (stream, event recorded on it after the last call)
+        self._range = None                   # device int32: the f16x2 kernels raise it when they clamp an activation
+        self._range_warned = False
+        self.strict_range = bool(kwargs.pop("strict_range", False)) or os.environ.get("VITS_STRICT_RANGE") == "1"
         c = N.VitsConfig()
         cfg = self.cfg
         c.n_vocab, c.hidden_channels, c.inter_channels = cfg.n_vocab, cfg.hidden_channels, cfg.inter_channels
@@ -180,8 +192,51 @@ class SynthesizerTrn:
                                                   prec),
                         f"set_conv {name}")
             N.check(N.lib.vits_model_finalize(h), "vits_model_finalize")
+            self._range = torch.zeros(1, dtype=torch.int32, device=self.device)
+            N.check(N.lib.vits_model_set_range_flag(h, self._range.data_ptr()), "set_range_flag")
             torch.cuda.synchronize(self.device)
+        self._last_use = None
         self._ready = True
+
+    # ---- single-stream, single-thread discipline ----
+    @contextlib.contextmanager
+    def _exclusive(self):
+        """Entered by every call that uses the model's workspace.  Raises if another thread is inside one; makes the
+        current stream wait for the previous call's work when that ran on a different stream."""
+        if not self._busy.acquire(blocking=False):
+            raise RuntimeError("vits_amd.SynthesizerTrn is not re-entrant: another thread is inside infer / "
+                               "infer_batches / voice_conversion on this model (use one model per thread)")
+        try:
+            cur = torch.cuda.current_stream(self.device)
+            if self._last_use is not None and self._last_use[0] != cur:
+                cur.wait_event(self._last_use[1])
+            yield
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._last_use = (torch.cuda.current_stream(self.device), ev)
+        finally:
+            self._busy.release()
+
+    def _report_range(self, flag: int) -> None:
+        if not flag:
+            return
+        msg = ("f16x2 generator kernels clamped activations to the fp16 range (|x| > 65504): this checkpoint's "
+               "generator leaves the range the default arithmetic covers and the waveform is saturated there; "
+               "build the model with precision=\"bf16x3\" (full fp32 range, same accuracy)")
+        if self.strict_range:
+            self._range.zero_()
+            raise OverflowError(msg)
+        if not self._range_warned:
+            self._range_warned = True
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+    def range_overflow(self) -> bool:
+        """True if any f16x2 kernel has clamped an activation to the fp16 range since the model was loaded
+        (synchronises the device).  infer itself reads the flag without an extra synchronisation, together with the
+        frame counts of the NEXT call, and then warns once (or raises OverflowError with strict_range=True)."""
+        if self._range is None:
+            return False
+        return bool(int(self._range.cpu()))
 
     # ---- workspace ----
     def _workspace(self, nbytes: int) -> torch.Tensor:
@@ -196,10 +251,11 @@ class SynthesizerTrn:
               pitch_control=None, duration_control=None, noise=None, stages: Optional[dict] = None):
         """reference models.py:717-767.  Extra keyword ``noise`` ([B, inter_channels, T]) replaces the
         torch.randn_like draw at :763; ``stages`` (a dict) receives stage-boundary tensors for tests."""
-        fe = self._frontend(phonemes, phonemes_lengths, sid, noise_scale, max_len, energy_control, pitch_control,
-                            duration_control, noise, stages)
-        B, T, t_dec, dev = fe["B"], fe["T"], fe["t_dec"], self.device
-        with torch.cuda.device(dev):
+        dev = self.device
+        with torch.cuda.device(dev), self._exclusive():
+            fe = self._frontend(phonemes, phonemes_lengths, sid, noise_scale, max_len, energy_control, pitch_control,
+                                duration_control, noise, stages)
+            B, T, t_dec = fe["B"], fe["T"], fe["t_dec"]
             stream = torch.cuda.current_stream(dev).cuda_stream
             ws = self._workspace(N.lib.vits_generator_workspace_bytes(self._handle, B, t_dec))
             o = torch.empty(B, 1, t_dec * self.total_upsample, dtype=torch.float32, device=dev)
@@ -217,63 +273,87 @@ class SynthesizerTrn:
         count) leaves most of the GPU idle, and the generator of the previous batch does not depend on it, so the two
         run on two streams with separate workspaces: while batch i's generator saturates the chip, batch i+1's front
         end fills the gaps.  Results are handed over on the caller's current stream (it waits on the generator's
-        event; no host synchronisation), one batch behind the submission."""
+        event; no host synchronisation), one batch behind the submission.
+
+        Streams: the caller's, the front-end stream, the generator stream and ONE library side stream for the
+        generator's ResBlock chains -- four in all, one hardware queue each (a HIP process has four by default, and
+        streams of different priority never share one).  With a fifth queue in play (two side streams) this mode was
+        seen to deadlock, so the generator is held to one side stream while it runs."""
         dev = self.device
-        if getattr(self, "_s_fe", None) is None or self._s_fe.device != dev:
-            # the front end's kernels are short and few blocks wide: on a high-priority stream they take the slots the
-            # generator's blocks free up instead of queueing behind whole generator launches
-            self._s_fe, self._s_gen = torch.cuda.Stream(dev, priority=int(os.environ.get("VITS_FE_PRIORITY", "-1"))), torch.cuda.Stream(dev)
-            self._ws_gen = None
+        if not self._busy.acquire(blocking=False):
+            raise RuntimeError("vits_amd.SynthesizerTrn is not re-entrant: another call is in progress on this model")
         lib, h = N.lib, self._handle
-        caller = torch.cuda.current_stream(dev)
-        # Every host tensor is uploaded before the two streams start: a blocking host-to-device copy issued while they
-        # were in flight was seen to hang on this stack (ROCm 7.2, high-priority stream), so none is issued then.
-        batches = [{k: (v.to(dev) if isinstance(v, torch.Tensor) and not v.is_cuda else v) for k, v in kw.items()}
-                   for kw in batches]
-        start = torch.cuda.Event()
-        start.record(caller)
-        self._s_fe.wait_event(start)                        # inputs prepared on the caller's stream are visible
-        self._s_gen.wait_event(start)
-        pending = None
-        for kw in batches:
-            kw = dict(kw)
-            args = (kw.pop("phonemes"), kw.pop("phonemes_lengths"))
-            with torch.cuda.stream(self._s_fe):
-                fe = self._frontend(*args, kw.pop("sid", None), kw.pop("noise_scale", 1), kw.pop("max_len", None),
-                                    kw.pop("energy_control", None), kw.pop("pitch_control", None),
-                                    kw.pop("duration_control", None), kw.pop("noise", None), None)
-                if kw:
-                    raise TypeError(f"unexpected arguments {sorted(kw)}")
-                fe_done = torch.cuda.Event()
-                fe_done.record(self._s_fe)
-            B, T, t_dec = fe["B"], fe["T"], fe["t_dec"]
-            if pending is not None:
-                # One generator call in flight at a time: the library forks and joins its ResBlock chains with one set
-                # of events per model, which must not be recorded again while the previous call still waits on them.
-                # The front end above has already been enqueued (and run) beside that call, so nothing is lost.
-                pending[2].synchronize()
-            # The front end is complete before its generator is enqueued (host wait, not a cross-stream one: a wait on
-            # the trailing marker of the high-priority stream was seen to deadlock against a blocking copy on the
-            # default stream).  The previous generator is still running or just finished, so the chip stays busy.
-            fe_done.synchronize()
-            with torch.cuda.device(dev), torch.cuda.stream(self._s_gen):
-                need = lib.vits_generator_workspace_bytes(h, B, t_dec)
-                if self._ws_gen is None or self._ws_gen.numel() < need:
+        try:
+            with torch.cuda.device(dev):
+                if getattr(self, "_s_fe", None) is None or self._s_fe.device != dev:
+                    # the front end's kernels are short and few blocks wide: on a high-priority stream they take the
+                    # slots the generator's blocks free up instead of queueing behind whole generator launches
+                    prio = int(os.environ.get("VITS_FE_PRIORITY", "-1"))
+                    self._s_fe, self._s_gen = torch.cuda.Stream(dev, priority=prio), torch.cuda.Stream(dev)
                     self._ws_gen = None
-                    self._ws_gen = torch.empty(int(need), dtype=torch.uint8, device=dev)
-                o = torch.empty(B, 1, t_dec * self.total_upsample, dtype=torch.float32, device=dev)
-                for t in (fe["z"], fe["totals"], fe["cond"]):
-                    t.record_stream(self._s_gen)             # allocated on the front-end stream, read here
-                N.check(lib.vits_generator(h, fe["z"].data_ptr(), fe["totals"].data_ptr(), fe["cond"].data_ptr(), B, T,
-                                           t_dec, o.data_ptr(), self._ws_gen.data_ptr(), self._ws_gen.numel(),
-                                           self._s_gen.cuda_stream), "generator")
-                gen_done = torch.cuda.Event()
-                gen_done.record(self._s_gen)
-            if pending is not None:
-                yield self._hand_over(*pending, caller)
-            pending = (o, fe, gen_done)
-        if pending is not None:
-            yield self._hand_over(*pending, caller)
+                caller = torch.cuda.current_stream(dev)
+                if self._last_use is not None and self._last_use[0] != caller:
+                    caller.wait_event(self._last_use[1])
+                N.check(lib.vits_model_set_generator_streams(h, int(os.environ.get("VITS_BATCHES_GEN_STREAMS", "2"))),
+                        "set_generator_streams")
+                # Every host tensor is uploaded before the side streams start, and the loop below issues no blocking
+                # host-to-device copy of its own.
+                batches = [{k: (v.to(dev) if isinstance(v, torch.Tensor) and not v.is_cuda else v) for k, v in kw.items()}
+                           for kw in batches]
+                start = torch.cuda.Event()
+                start.record(caller)
+                self._s_fe.wait_event(start)                    # inputs prepared on the caller's stream are visible
+                self._s_gen.wait_event(start)
+                pending = None
+                for kw in batches:
+                    kw = dict(kw)
+                    args = (kw.pop("phonemes"), kw.pop("phonemes_lengths"))
+                    with torch.cuda.stream(self._s_fe):
+                        fe = self._frontend(*args, kw.pop("sid", None), kw.pop("noise_scale", 1), kw.pop("max_len", None),
+                                            kw.pop("energy_control", None), kw.pop("pitch_control", None),
+                                            kw.pop("duration_control", None), kw.pop("noise", None), None)
+                        if kw:
+                            raise TypeError(f"unexpected arguments {sorted(kw)}")
+                        fe_done = torch.cuda.Event()
+                        fe_done.record(self._s_fe)
+                    B, T, t_dec = fe["B"], fe["T"], fe["t_dec"]
+                    if pending is not None:
+                        # One generator call in flight at a time: the library forks and joins its ResBlock chains with
+                        # one set of events per model, which must not be recorded again while the previous call still
+                        # waits on them.  The front end above has already been enqueued (and run) beside that call.
+                        pending[2].synchronize()
+                    # The front end is complete before its generator is enqueued (a host wait: the generator stream
+                    # then holds no barrier on another queue's marker).  The previous generator is still running or
+                    # just finished, so the chip stays busy.
+                    fe_done.synchronize()
+                    with torch.cuda.stream(self._s_gen):
+                        need = lib.vits_generator_workspace_bytes(h, B, t_dec)
+                        if self._ws_gen is None or self._ws_gen.numel() < need:
+                            self._ws_gen = None
+                            self._ws_gen = torch.empty(int(need), dtype=torch.uint8, device=dev)
+                        o = torch.empty(B, 1, t_dec * self.total_upsample, dtype=torch.float32, device=dev)
+                        for t in (fe["z"], fe["totals"], fe["cond"]):
+                            t.record_stream(self._s_gen)         # allocated on the front-end stream, read here
+                        N.check(lib.vits_generator(h, fe["z"].data_ptr(), fe["totals"].data_ptr(), fe["cond"].data_ptr(),
+                                                   B, T, t_dec, o.data_ptr(), self._ws_gen.data_ptr(),
+                                                   self._ws_gen.numel(), self._s_gen.cuda_stream), "generator")
+                        gen_done = torch.cuda.Event()
+                        gen_done.record(self._s_gen)
+                    if pending is not None:
+                        yield self._hand_over(*pending, caller)
+                    pending = (o, fe, gen_done)
+                if pending is not None:
+                    yield self._hand_over(*pending, caller)
+        finally:
+            # whatever ends the loop (exhaustion, an exception, the consumer dropping the generator): the next call on
+            # this model starts after both side streams have drained, with the default stream count restored
+            if getattr(self, "_s_fe", None) is not None:
+                ev = torch.cuda.Event()
+                self._s_gen.wait_stream(self._s_fe)
+                ev.record(self._s_gen)
+                self._last_use = (self._s_gen, ev)
+            lib.vits_model_set_generator_streams(h, 8)
+            self._busy.release()
 
     @staticmethod
     def _hand_over(o, fe, gen_done, caller):
@@ -299,8 +379,9 @@ class SynthesizerTrn:
         rest of infer()'s tuple (x_mask, (z, z_p, m_p, logs_p), duration, F0, energy)."""
         if chunk_frames <= 0:
             raise ValueError("chunk_frames must be positive")
-        fe = self._frontend(phonemes, phonemes_lengths, sid, noise_scale, max_len, energy_control, pitch_control,
-                            duration_control, noise, None)
+        with torch.cuda.device(self.device), self._exclusive():
+            fe = self._frontend(phonemes, phonemes_lengths, sid, noise_scale, max_len, energy_control, pitch_control,
+                                duration_control, noise, None)
         return InferStream(self, fe, int(chunk_frames))
 
     @torch.no_grad()
@@ -322,7 +403,7 @@ class SynthesizerTrn:
             raise ValueError("at most 2048 frames per utterance")
         IC = self.cfg.inter_channels
         f32 = dict(dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), self._exclusive():
             stream = torch.cuda.current_stream(dev).cuda_stream
             spec = torch.zeros(B, pc, T, **f32)                  # channel count rounded up to a multiple of 16
             spec[:, :S] = y.to(dev, torch.float32)
@@ -441,12 +522,15 @@ class SynthesizerTrn:
             totals = torch.empty(B, dtype=torch.int32, device=dev)
             N.check(lib.vits_length_regulate_plan(d.data_ptr(), _DUR_DTYPES[d.dtype], B, P, cum.data_ptr(),
                                                   totals.data_ptr(), stream), "length_regulate_plan")
-            host = torch.cat([totals, err]).cpu()          # synchronises the stream
-            if int(host[-1]) & 1:
+            # one device-to-host copy: frame counts, id-range errors, and the fp16-range flag that generator calls
+            # before this one may have raised (synchronises the stream)
+            host = torch.cat([totals, err, self._range]).cpu()
+            if int(host[-2]) & 1:
                 raise IndexError("phoneme id out of range of the symbol table")
-            if int(host[-1]) & 2:
+            if int(host[-2]) & 2:
                 raise IndexError("speaker id out of range")
-            T = int(host[:-1].max())
+            self._report_range(int(host[-1]))
+            T = int(host[:-2].max())
             if T <= 0:
                 raise ValueError("all durations are zero: nothing to synthesise")
             x_frame = torch.empty(B, Cc, T, **f32)
@@ -536,11 +620,13 @@ class InferStream:
                 e = min(s + self.chunk_frames, t_dec)
                 s0, e0 = max(0, s - H), min(t_dec, e + H)          # window + context; the utterance's own ends stay
                 n = e0 - s0
-                stream = torch.cuda.current_stream(dev).cuda_stream
-                ws = net._workspace(lib.vits_generator_workspace_bytes(h, B, n))
-                lens = (fe["totals"] - s0).clamp_(min=0)           # the length mask, relative to the window start
-                o = torch.empty(B, 1, n * up, dtype=torch.float32, device=dev)
-                # window of z: same row stride T, start shifted by s0 frames
-                N.check(lib.vits_generator(h, z.data_ptr() + 4 * s0, lens.data_ptr(), fe["cond"].data_ptr(), B, T, n,
-                                           o.data_ptr(), ws.data_ptr(), ws.numel(), stream), "generator (window)")
+                with net._exclusive():                             # the lock is free again between windows
+                    stream = torch.cuda.current_stream(dev).cuda_stream
+                    ws = net._workspace(lib.vits_generator_workspace_bytes(h, B, n))
+                    lens = (fe["totals"] - s0).clamp_(min=0)       # the length mask, relative to the window start
+                    o = torch.empty(B, 1, n * up, dtype=torch.float32, device=dev)
+                    # window of z: same row stride T, start shifted by s0 frames
+                    N.check(lib.vits_generator(h, z.data_ptr() + 4 * s0, lens.data_ptr(), fe["cond"].data_ptr(), B, T,
+                                               n, o.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                            "generator (window)")
                 yield s * up, o[:, :, (s - s0) * up:(e - s0) * up]
