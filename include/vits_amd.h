@@ -172,7 +172,7 @@ int vits_profile_read_bytes(int index, double* bytes);
  * 16 += res, 32 res - result, 64 += out, 128 mask last, 256 write the result in the staged operand format of the next
  * conv (leaky-relu(in_slope) applied, converted; plain convs in precision 2 / 3 only), 512 the input is in that format.
  * Staged format, per batch row: 16-byte units of eight channels of one time step, precision 2: bf16 [C/8][L][8];
- * precision 3: fp16 [C/8][L][2 planes h, l][8]. */
+ * precision 3: fp16 [C/8][2 planes h, l][L][8]. */
 /* Device int32 the f16x2 single operators below OR 1 into when they clamp an activation to the fp16 range (thread-local
  * setting; NULL, the default, switches it off). */
 void vits_op_set_range_flag(int* dev_flag);

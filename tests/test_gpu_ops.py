@@ -186,7 +186,7 @@ def test_conv_split_schemes_over_a_wide_dynamic_range(N, pname, bound):
 @pytest.mark.parametrize("C,k,dil,L,B", [(64, 7, 3, 3000, 2), (128, 3, 1, 700, 3), (32, 11, 5, 1500, 2), (256, 3, 1, 90, 2)])
 def test_conv_staged_pair(N, pname, C, k, dil, L, B):
     """A ResBlock pair with the tensor between the two convs in the second conv's staged operand format: the first
-    conv writes leaky-relu(result) converted (bf16: [C/8][L][8]; f16x2: [C/8][L][h, l][8] fp16), the second copies it
+    conv writes leaky-relu(result) converted (bf16: [C/8][L][8]; f16x2: [C/8][h, l][L][8] fp16), the second copies it
     into LDS as is.  The values are those the unstaged pair converts at staging, so the final result is bit-identical;
     the staged bytes are decoded and checked too."""
     from vits_amd import weights
@@ -220,9 +220,9 @@ def test_conv_staged_pair(N, pname, C, k, dil, L, B):
         got = flat[:B * C * L // 2].contiguous().view(torch.bfloat16).reshape(B, C // 8, L, 8)
         assert torch.equal(got.permute(0, 1, 3, 2).reshape(B, C, L).float(), act.to(torch.bfloat16).float())
     else:
-        got = flat.contiguous().view(torch.float16).reshape(B, C // 8, L, 2, 8)
-        h = got[:, :, :, 0].permute(0, 1, 3, 2).reshape(B, C, L).float()
-        lo = got[:, :, :, 1].permute(0, 1, 3, 2).reshape(B, C, L).float()
+        got = flat.contiguous().view(torch.float16).reshape(B, C // 8, 2, L, 8)
+        h = got[:, :, 0].permute(0, 1, 3, 2).reshape(B, C, L).float()
+        lo = got[:, :, 1].permute(0, 1, 3, 2).reshape(B, C, L).float()
         assert torch.equal(h, act.to(torch.float16).float())
         assert torch.equal(lo, (act - h).to(torch.float16).float())
 

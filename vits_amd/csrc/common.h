@@ -36,8 +36,9 @@ enum ConvFlags : int {
   F_MASK_POST = 1 << 7,   // result *= mask last
   // Staged activations (MODE_PLAIN, PREC_BF16 / PREC_F16X2 only): a tensor that only the next conv reads is written
   // by its producer already in that conv's LDS operand format -- leaky-relu(out_slope) applied, converted, eight
-  // channels of one time step per 16-byte unit: bf16 [C/8][L][8], f16x2 [C/8][L][2 planes][8] -- so the consumer
-  // stages it with plain 16-byte copies (no prologue, no conversion).  x_bs / out_bs stay in floats.
+  // channels of one time step per 16-byte unit: bf16 [C/8][L][8], f16x2 [C/8][2 planes h, l][L][8] (a plane of a channel
+  // group is one contiguous run over time, which LDS-DMA copies 64 time steps at a time) -- so the consumer stages
+  // it with plain 16-byte copies (no prologue, no conversion).  x_bs / out_bs stay in floats.
   F_OUT_STAGED = 1 << 8,  // write the result in staged format (bias / conditioning bias only; no residual, mask, accumulate)
   F_IN_STAGED  = 1 << 9,  // the input is in staged format
 };
@@ -75,6 +76,8 @@ struct ConvArgs {
   float in_scale, in_slope;
   float out_slope;                                   // F_OUT_STAGED: leaky-relu slope the consumer would apply
   int toff0[2], tstep[2];                            // tap k reads x[t + toff0 + k * tstep] (per row class)
+  float* out2; long long out2_bs;                    // MODE_PLAIN, optional: a second copy of the result in the staged
+                                                     // f16x2 format (leaky-relu(out_slope) applied), for the next conv
   int* range_flag;                                   // PREC_F16X2: OR 1 into *range_flag when an activation lies outside
                                                      // the fp16 range and was clamped (null: not reported)
 };
@@ -134,6 +137,9 @@ hipError_t launch_energy_math(const float* in, bool in_is_raw, float scale, floa
                               hipStream_t s);
 hipError_t launch_sample(const float* stats, const float* noise, float noise_scale, float* z_p, float* z, int B, int C,
                          int L, hipStream_t s, const int* lengths = nullptr);
+// x [B, C, L] fp32 -> staged f16x2 operand format [B][C/8][2 planes][L][8 fp16] of leaky-relu(x * scale, slope)
+hipError_t launch_stage_f16x2(const float* x, float* out, int B, int C, int L, float scale, float slope, int* range_flag,
+                              hipStream_t s);
 // length regulator
 hipError_t launch_lr_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, hipStream_t s);
 hipError_t launch_lr_gather(const float* x, const int* cum, const int* totals, float* out, int B, int C, int P, int T,

@@ -30,6 +30,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace vits {
@@ -92,8 +93,48 @@ int prof_collect(std::vector<ProfRow>& rows) {
   return (int)rows.size();
 }
 
+int device_cu_count();
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// f16x2 operands are clamped to the fp16 range at conversion; a caller that wants to know passes a device word, and
+// every thread that clamped a value ORs 1 into it (a not-taken branch otherwise).
+__device__ __forceinline__ void report_f16_range(int* flag, float amax) {
+  if (flag && !(amax <= 65504.f)) atomicOr(flag, 1);
+}
+
+// The 16 values a lane holds of one 32 x 32 accumulator tile (m-tile mt, its column at time t) -> the staged f16x2
+// format [C/8][2 planes][L] of 16-byte units: leaky-relu(out_slope), clamp, h = fp16(v), l = fp16(v - h).  Register
+// group g holds channels 8g + 4*par .. + 3: half a unit, one 8-byte store per plane.
+__device__ __forceinline__ void staged_f16x2_store(const ConvArgs& a, const float (&fv)[16], uint2* out_b, int mt, int par,
+                                                   int t) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float e = fv[4 * g + q];
+      v[q] = fmaxf(e, e * a.out_slope);
+    }
+    report_f16_range(a.range_flag, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    const long long unit = (long long)(mt * 4 + g) * 2 * a.L + t;
+    uint2 oh, ol;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x2 e = {fminf(fmaxf(v[2 * u], -65504.f), 65504.f), fminf(fmaxf(v[2 * u + 1], -65504.f), 65504.f)};
+      const f16x2 h = __builtin_convertvector(e, f16x2);
+      const f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, f32x2), f16x2);
+      (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, h);
+      (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, l);
+    }
+    out_b[unit * 2 + par] = oh;
+    out_b[(unit + a.L) * 2 + par] = ol;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Epilogue shared by both arithmetic modes (the 32x32 C/D layout does not depend on the operand type).
@@ -166,6 +207,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
             for (int r = 0; r < 16; ++r)
               ov[r] = (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out];
           }
+          float fv[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[i][j][r] + bz[r];
@@ -175,8 +217,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
             if (a.flags & F_RES_SUB) v = rv[ri][j][r] - v;
             if (a.flags & F_ACCUM) v += ov[r];
             if (a.flags & F_MASK_POST) v *= m;
+            fv[r] = v;
             (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = v;
           }
+          if (a.out2) staged_f16x2_store(a, fv, reinterpret_cast<uint2*>(a.out2 + (long long)b * a.out2_bs), mt[i], par, t);
         }
       }
     }
@@ -648,7 +692,6 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // helpers shared by the bf16x3 kernels below
 // ---------------------------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // (v0, v1) -> packed bf16 pairs h, m, l with v = h + m + l exactly (low half = v0)
@@ -663,15 +706,6 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, uns
 
 template <int V>
 struct IntC { static constexpr int value = V; };
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-// f16x2 operands are clamped to the fp16 range at conversion; a caller that wants to know passes a device word, and
-// every thread that clamped a value ORs 1 into it (a not-taken branch otherwise).
-__device__ __forceinline__ void report_f16_range(int* flag, float amax) {
-  if (flag && !(amax <= 65504.f)) atomicOr(flag, 1);
-}
 
 // Epilogue for F_OUT_STAGED (MODE_PLAIN): result + bias (+ conditioning bias) -> leaky-relu(out_slope) -> the consumer's
 // operand format.  A lane holds, per 8-row group g of an m-tile, the four channels 8g + 4*par .. + 3 of its time step:
@@ -705,7 +739,8 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x16 (
           e = fmaxf(e, e * a.out_slope);
           v[q] = e;
         }
-        const long long unit = (long long)(mt[i] * 4 + g) * a.L + t;         // 16-byte unit of (channel group, t)
+        // 16-byte unit of (channel group cg, plane p, time t): ((cg * PLANES + p) * L + t)
+        const long long unit = (long long)(mt[i] * 4 + g) * PLANES * a.L + t;
         if constexpr (PLANES == 1) {
           uint2 o;
           o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
@@ -722,8 +757,8 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, f32x16 (
             (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, h);
             (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, l);
           }
-          out_b[(unit * 2 + 0) * 2 + par] = oh;
-          out_b[(unit * 2 + 1) * 2 + par] = ol;
+          out_b[unit * 2 + par] = oh;
+          out_b[(unit + a.L) * 2 + par] = ol;
         }
       }
     }
@@ -782,7 +817,7 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
           for (int p = 0; p < NPU; ++p)
-            sp[q][hf * NPU + p] = xs[((long long)(chunk * 2 + hf) * a.L + (ok ? t : 0)) * NPU + p];
+            sp[q][hf * NPU + p] = xs[((long long)(chunk * 2 + hf) * NPU + p) * a.L + (ok ? t : 0)];
       }
       return;
     }
@@ -976,7 +1011,7 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
           for (int p = 0; p < NPU; ++p)
-            sp[q][hf * NPU + p] = xs[((long long)(chunk * 2 + hf) * a.L + (ok ? t : 0)) * NPU + p];
+            sp[q][hf * NPU + p] = xs[((long long)(chunk * 2 + hf) * NPU + p) * a.L + (ok ? t : 0)];
       }
       return;
     }
@@ -1192,6 +1227,227 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// PREC_F16X2 with a staged input, every operand through LDS by LDS-DMA (conv_gl_kernel; MODE_PLAIN, K taps known at
+// compile time).
+//
+// A CU's vector-memory results come back in issue order, so a weight fragment requested one tap ahead (an L2 hit)
+// returns behind whatever activation tile some wave of the CU is streaming from memory, and the matrix pipe idles for
+// that round trip on every tap.  Here no value the tap loop needs is requested less than D taps ahead, and none of
+// it passes through registers on its way in:
+//   * weights of one (chunk, tap) step for the block's BM rows are one contiguous run of the packed stream
+//     ([M/32][2 planes][64 lanes] 16-byte units): BM * 64 bytes, copied by `buffer_load_dwordx4 ... lds` into a ring of
+//     S = D + 1 slots, D steps ahead of their use;
+//   * the staged activations of a 16-channel chunk ([2 halves][2 planes] runs over time, see F_OUT_STAGED) are copied
+//     the same way, A chunks ahead, into one of A + 1 buffers; lanes outside [0, L) lie outside the buffer
+//     descriptor's range and deliver zeros, which is the convolution's padding;
+//   * a step is: counted s_waitcnt vmcnt (everything older than the last D - 1 steps has landed) -> s_barrier (every
+//     wave's share has) -> fragment reads (ds_read_b128, conflict-free) -> the DMA requests of step + D into the slot
+//     the barrier has just released -> 12 MFMAs.
+// The DMA pattern is the same at every step (indices are clamped at the end, the first D steps' requests are issued
+// before the loop in the order the loop would have issued them), so the counts are compile-time constants.
+// Same operands in the same order as conv_f16x2_kernel: bit-identical results.
+// Block = 4 waves (WGM x WGN), wave tile 64 x 64, two blocks to a CU.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+typedef unsigned gl_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int gl_floor_mod(int x, int m) { return ((x % m) + m) % m; }
+constexpr int gl_floor_div(int x, int m) { return (x - gl_floor_mod(x, m)) / m; }
+// activation tiles requested during the D - 1 steps before tap k (requests go out at tap 0 of a chunk)
+constexpr int gl_tap0_in_window(int k, int K, int D) {
+  int n = 0;
+  for (int j = 1; j <= D - 1; ++j) n += gl_floor_mod(k - j, K) == 0 ? 1 : 0;
+  return n;
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void gl_static_for(F& f) {
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    gl_static_for<I + 1, N>(f);
+  }
+}
+
+template <int WN, int WGM, int WGN, int K, int D, int A>
+__global__ __launch_bounds__(256, 2) void conv_gl_kernel(const ConvArgs a) {
+  constexpr int WM = 2;
+  constexpr int BM = 64 * WGM, BN = 32 * WN * WGN;
+  static_assert(WN == 2 || WN == 4, "wave tile 64 x 64 or 64 x 128");
+  constexpr int S = D + 1, NBUF = A + 1;
+  constexpr int NCOLS = BN + MAX_HALO;           // tile columns: a multiple of 64, halo included
+  constexpr int WU = BM * 4;                     // 16-byte units of one step's weights
+  constexpr int WPK = WU / 64 / 4;               // weight DMA instructions per wave and step
+  constexpr int APC = NCOLS / 64;                // activation DMA instructions per wave and chunk (wave w copies slab w)
+  static_assert(WGM * WGN == 4, "four waves per block");
+  static_assert(A * K >= D, "an activation tile must have left the request window when it is first read");
+  static_assert(WU % 256 == 0 && NCOLS % 64 == 0, "whole wave-instructions");
+
+  extern __shared__ __attribute__((aligned(16))) uint4 gl_lds[];
+  uint4* wq = gl_lds;                            // [S][BM/32][2 planes][64 lanes]
+  uint4* xq = gl_lds + S * WU;                   // [NBUF][2 halves][2 planes][NCOLS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int par = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BN;
+  const int mt0 = blockIdx.y * (BM / 32);
+  int mt[WM];
+  bool mt_ok[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    mt[i] = mt0 + wm * WM + i;
+    mt_ok[i] = true;                             // the launcher only takes M % BM == 0
+  }
+  const int nchunks = a.Cin / 16;
+  const int total = nchunks * K;
+  const int tstart = t0 + a.min_off;
+  const int dil = a.tstep[0];
+
+  // ---- DMA requests ----
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.Cin * K * a.M * 4, 0x00020000);
+  const uint4* xs_b = reinterpret_cast<const uint4*>(a.x + (long long)b * a.x_bs);
+  auto issue_w = [&](int s, int slot) __attribute__((always_inline)) {
+    const int sc = s < total ? s : total - 1;
+    const int unit0 = (sc * a.mt_total + mt0) * 128;
+#pragma unroll
+    for (int j = 0; j < WPK; ++j) {
+      const int piece = wave + 4 * j;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(wq + slot * WU + piece * 64), 16,
+                                               (unit0 + piece * 64 + lane) * 16, 0, 0, 0);
+    }
+  };
+  auto issue_x = [&](int c, int buf) __attribute__((always_inline)) {
+    const int cc = c < nchunks ? c : nchunks - 1;
+    // this wave's slab: channel group 2 * cc + (wave >> 1), plane wave & 1; its run over time is one buffer, so that
+    // t < 0 and t >= L are out of range and read as zero
+    const uint4* slab = xs_b + (long long)((cc * 2 + (wave >> 1)) * 2 + (wave & 1)) * a.L;
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(slab), 0, a.L * 16, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < APC; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(xq + (buf * 4 + wave) * NCOLS + 64 * j), 16,
+                                               (tstart + 64 * j + lane) * 16, 0, 0, 0);
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- the requests of the steps before the first one, in the loop's own order ----
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    if ((c - A) * K < -D) issue_x(c, c % NBUF);
+#pragma unroll
+  for (int v = -D; v < 0; ++v) {
+    if (gl_floor_mod(v, K) == 0) issue_x(gl_floor_div(v, K) + A, (gl_floor_div(v, K) + A) % NBUF);
+    issue_w(v + D, (v + D) % S);
+  }
+
+  auto mma = [&](const gl_u32x4 (&af)[WM], const gl_u32x4 (&bf)[WN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]),
+                                                           __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
+  };
+
+  int slot_rd = 0, slot_wr = D % S;              // ring slot of the current step, and of step + D
+  int buf_rd = 0, buf_wr = A % NBUF;             // buffer of the current chunk, and of chunk + A
+  // Fragment reads are written as ds_read_b128 statements of our own: a read the compiler can see is made to wait for
+  // EVERY LDS-DMA request in flight (it cannot tell the ring slots apart), which would drain the look-ahead at every
+  // step.  Byte addresses: fragment (m-tile i, plane p) of a slot at a_addr + (2 * i + p) * 1024; activation unit
+  // (half par, plane p, column) at b_addr + p * NCOLS * 16 + 512 * j, tap k a further k * dil * 16.
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_void*)gl_lds;
+  const unsigned a_addr = lds_base + (unsigned)(((wm * WM * 2) * 64 + lane) * 16);
+  const unsigned b_addr = lds_base + (unsigned)((S * WU + par * 2 * NCOLS + wn * 32 * WN + l31) * 16);
+  int s = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const unsigned xb = b_addr + (unsigned)(buf_rd * 4 * NCOLS * 16);
+    auto tap = [&](auto kk) __attribute__((always_inline)) {
+      constexpr int k = decltype(kk)::value;
+      constexpr int allowed = (D - 1) * WPK + APC * gl_tap0_in_window(k, K, D);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allowed) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const unsigned wa = a_addr + (unsigned)(slot_rd * WU * 16);
+      const unsigned xk = xb + (unsigned)(k * dil * 16);
+      gl_u32x4 ah0, al0, ah1, al1, bh0, bh1, bh2, bh3, bl0, bl1, bl2, bl3;
+      asm volatile(
+          "ds_read_b128 %0, %4\n\t"
+          "ds_read_b128 %1, %4 offset:1024\n\t"
+          "ds_read_b128 %2, %4 offset:2048\n\t"
+          "ds_read_b128 %3, %4 offset:3072"
+          : "=&v"(ah0), "=&v"(al0), "=&v"(ah1), "=&v"(al1)
+          : "v"(wa)
+          : "memory");
+      asm volatile(
+          "ds_read_b128 %0, %4\n\t"
+          "ds_read_b128 %1, %4 offset:512\n\t"
+          "ds_read_b128 %2, %4 offset:%c5\n\t"
+          "ds_read_b128 %3, %4 offset:%c6"
+          : "=&v"(bh0), "=&v"(bh1), "=&v"(bl0), "=&v"(bl1)
+          : "v"(xk), "i"(NCOLS * 16), "i"(NCOLS * 16 + 512)
+          : "memory");
+      if constexpr (WN == 4)
+        asm volatile(
+            "ds_read_b128 %0, %4 offset:1024\n\t"
+            "ds_read_b128 %1, %4 offset:1536\n\t"
+            "ds_read_b128 %2, %4 offset:%c5\n\t"
+            "ds_read_b128 %3, %4 offset:%c6"
+            : "=&v"(bh2), "=&v"(bh3), "=&v"(bl2), "=&v"(bl3)
+            : "v"(xk), "i"(NCOLS * 16 + 1024), "i"(NCOLS * 16 + 1536)
+            : "memory");
+      // the DMA requests of the steps ahead go out while the fragment reads are in flight
+      if constexpr (k == 0) issue_x(c + A, buf_wr);
+      issue_w(s + D, slot_wr);
+      // the wait names every fragment register, so nothing touches them before the reads have landed, and the
+      // scheduling barrier keeps the MFMAs (register-only, not ordered by a memory clobber) below it
+      if constexpr (WN == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ah0), "+v"(al0), "+v"(ah1), "+v"(al1), "+v"(bh0), "+v"(bh1), "+v"(bl0), "+v"(bl1), "+v"(bh2),
+                       "+v"(bh3), "+v"(bl2), "+v"(bl3)
+                     :
+                     : "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ah0), "+v"(al0), "+v"(ah1), "+v"(al1), "+v"(bh0), "+v"(bh1), "+v"(bl0), "+v"(bl1)
+                     :
+                     : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const gl_u32x4 Ah[WM] = {ah0, ah1}, Al[WM] = {al0, al1};
+      gl_u32x4 Bh[WN], Bl[WN];
+      Bh[0] = bh0; Bh[1] = bh1; Bl[0] = bl0; Bl[1] = bl1;
+      if constexpr (WN == 4) { Bh[2] = bh2; Bh[3] = bh3; Bl[2] = bl2; Bl[3] = bl3; }
+      mma(Ah, Bl);                                       // h * l
+      mma(Ah, Bh);                                       // h * h
+      mma(Al, Bh);                                       // l * h
+      ++s;
+      slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
+      slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
+    };
+    gl_static_for<0, K>(tap);
+    buf_rd = buf_rd + 1 == NBUF ? 0 : buf_rd + 1;
+    buf_wr = buf_wr + 1 == NBUF ? 0 : buf_wr + 1;
+  }
+  // nothing of this block may still be on its way into LDS when the block's LDS is handed to the next one
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (a.flags & F_OUT_STAGED) {
+    conv_epilogue_staged<WM, WN, 2>(a, acc, mt, mt_ok, wn, par, l31, t0, b);
+    return;
+  }
+  // residual loads one 32-row block ahead of its stores for the 64 x 128 wave tile (the whole tile's would not fit in
+  // registers beside the accumulators)
+  conv_epilogue<WM, WN, MODE_PLAIN, WN == 2>(a, acc, mt, mt_ok, wn, par, l31, t0, b, a.lengths ? a.lengths[b] : 0x7fffffff);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 template <typename Launch>
@@ -1222,7 +1478,7 @@ static hipError_t timed_launch(const char* name, bool gate, const ConvArgs& a, h
                           : strstr(name, "conv_bf16_kernel") ? 2.0 : 6.0;
     const double sb = strstr(name, "conv_bf16_kernel") ? 2.0 : 4.0;           // bytes per staged element
     const double in_b = (a.flags & F_IN_STAGED) ? sb : 4.0, out_b = (a.flags & F_OUT_STAGED) ? sb : 4.0;
-    c.bytes += (double)a.L * a.B * (in_b * a.Cin + outs * (out_b + 4.0 * reads)) + wbytes * a.M * a.Cin * a.K;
+    c.bytes += (double)a.L * a.B * (in_b * a.Cin + outs * (out_b + 4.0 * reads + (a.out2 ? 4.0 : 0.0))) + wbytes * a.M * a.Cin * a.K;
     c.count += 1;
     c.pending.emplace_back(e0, e1);
   }
@@ -1284,7 +1540,6 @@ static hipError_t launch_b1(ConvArgs& a, hipStream_t stream) {
 }
 
 constexpr int F16X2_RING = 6;
-int device_cu_count();
 // The ring variant takes grids of at most VITS_CONV_RING blocks per CU (default 2, what its register count lets be
 // resident; 0 keeps every launch on the occupancy-oriented kernel, for A/B measurements).
 static int f16x2_ring_blocks_per_cu() {
@@ -1295,8 +1550,77 @@ static int f16x2_ring_blocks_per_cu() {
   return n;
 }
 
+// VITS_CONV_GL=0 keeps staged-input convs on the register-staged kernel (A/B measurements).
+static bool gl_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_CONV_GL");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+template <int WN, int WGM, int WGN, int K, int D, int A>
+static hipError_t launch_gl_cfg(ConvArgs& a, hipStream_t stream) {
+  constexpr int BM = 64 * WGM, BN = 32 * WN * WGN;
+  constexpr size_t lds = ((size_t)(D + 1) * BM * 4 + (size_t)(A + 1) * 4 * (BN + MAX_HALO)) * sizeof(uint4);
+  static bool attr_set = false;                  // more than 64 KiB of dynamic LDS has to be asked for once per kernel
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gl_kernel<WN, WGM, WGN, K, D, A>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid((a.L + BN - 1) / BN, a.M / BM, a.B);
+  char name[96];
+  snprintf(name, sizeof name, "conv_gl_kernel<%d,%d,%d,%d>", WN, WGM, WGN, K);
+  return timed_launch(name, false, a, stream, [&] {
+    hipLaunchKernelGGL((conv_gl_kernel<WN, WGM, WGN, K, D, A>), grid, dim3(256), lds, stream, a);
+  });
+}
+
+// VITS_CONV_GL_WIDE=0: 128 x 128 block tiles for the >= 128-row layers instead of 128 x 256 (A/B measurements).
+static bool gl_wide() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_CONV_GL_WIDE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// Staged-input plain convs of the generator (3, 7 or 11 taps) whose grid fills the chip go to the LDS-DMA kernel.
+// What bounds it is the CU's load path: every block pulls the whole packed weight stream through it once per output
+// tile, so tiles are as wide in time as two blocks' LDS allows -- 128 rows x 256 steps (wave tile 64 x 128) when the
+// rows allow, else 64 x 256.  Returns false when the launch is not one of them.
+static bool try_launch_gl(ConvArgs& a, hipStream_t stream, hipError_t& err) {
+  if (!gl_enabled() || !(a.flags & F_IN_STAGED) || a.in_cbias || a.cbias || (a.flags & (F_IN_MASK | F_IN_LRELU))) return false;
+  if (a.M % 64 || (a.K != 3 && a.K != 7 && a.K != 11) || a.tstep[0] < 1) return false;
+  if ((long long)a.Cin * a.K * a.M * 4 >= (1LL << 31) || (long long)a.L * 16 >= (1LL << 31)) return false;
+  const bool tall = a.M % 128 == 0;
+  auto blocks_of = [&](int bn) { return (long long)((a.L + bn - 1) / bn) * (a.M / (tall ? 128 : 64)) * a.B; };
+  const long long slots = 2LL * device_cu_count();            // two blocks to a CU
+  // 128 x 256 tiles when that still gives every slot a block, else 128 x 128; a grid that cannot even give every CU a
+  // block stays with the register-ring variant of the other kernel (batch-1 latency)
+  const bool wide = tall && gl_wide() && blocks_of(256) > slots;
+  if (blocks_of(wide || !tall ? 256 : 128) <= slots / 2) return false;
+  // look-ahead D steps; the activation tile goes out A chunks ahead with A * K >= D
+  if (wide)
+    err = a.K == 3 ? launch_gl_cfg<4, 2, 2, 3, 3, 1>(a, stream) : a.K == 7 ? launch_gl_cfg<4, 2, 2, 7, 3, 1>(a, stream)
+                                                                          : launch_gl_cfg<4, 2, 2, 11, 3, 1>(a, stream);
+  else if (tall)
+    err = a.K == 3 ? launch_gl_cfg<2, 2, 2, 3, 4, 2>(a, stream) : a.K == 7 ? launch_gl_cfg<2, 2, 2, 7, 4, 1>(a, stream)
+                                                                          : launch_gl_cfg<2, 2, 2, 11, 4, 1>(a, stream);
+  else
+    err = a.K == 3 ? launch_gl_cfg<2, 1, 4, 3, 4, 2>(a, stream) : a.K == 7 ? launch_gl_cfg<2, 1, 4, 7, 4, 1>(a, stream)
+                                                                          : launch_gl_cfg<2, 1, 4, 11, 4, 1>(a, stream);
+  return true;
+}
+
 template <int WM, int WN, int WGM, int WGN, int MODE>
 static hipError_t launch_h2(ConvArgs& a, hipStream_t stream) {
+  if constexpr (MODE == MODE_PLAIN) {
+    hipError_t err = hipSuccess;
+    if (try_launch_gl(a, stream, err)) return err;
+  }
   constexpr int BN = 32 * WN * WGN;
   a.width = BN + (a.width);
   a.rs = a.width;                    // columns per (plane, half) slab
@@ -1686,6 +2010,7 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   if ((a.flags & F_OUT_STAGED) && (a.flags & (F_RELU | F_MASK_PRE | F_RES | F_RES_SUB | F_ACCUM | F_MASK_POST)))
     return hipErrorInvalidValue;
   if ((a.flags & (F_IN_STAGED | F_OUT_STAGED)) && (d.Cin % 16 || M % 32)) return hipErrorInvalidValue;
+  if (a.out2 && (d.mode != MODE_PLAIN || p != PREC_F16X2 || (a.flags & F_OUT_STAGED))) return hipErrorInvalidValue;
   if (p == PREC_BF16X3 && (d.mode == MODE_PLAIN || d.mode == MODE_GATE)) {
     hipError_t err = hipSuccess;
     ConvArgs ak = a;

@@ -626,6 +626,54 @@ hipError_t launch_sample(const float* stats, const float* noise, float noise_sca
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// fp32 activations -> the staged f16x2 operand format of the conv kernels: y = leaky-relu(x * scale, slope) clamped to
+// the fp16 range, h = fp16(y), l = fp16(y - h), written as [B][C/8][2 planes h, l][L] 16-byte units of eight channels
+// (the input prologue of the ResBlock convs, reference modules.py:208-209, applied once for all three ResBlocks that
+// read the same tensor).  A thread owns one (channel group, time step): eight coalesced loads, two 16-byte stores.
+// ---------------------------------------------------------------------------------------------------------
+typedef float st_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 st_f16x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void stage_f16x2_kernel(const float* __restrict__ x, uint4* __restrict__ out, int C, int L,
+                                                          float scale, float slope, int* range_flag) {
+  const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  if (t >= L) return;
+  const float* xb = x + ((long long)b * C + cg * 8) * L + t;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = xb[(long long)i * L];
+  unsigned ph[4], pl[4];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st_f32x2 e;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float y = v[2 * i + u] * scale;
+      y = fmaxf(y, y * slope);
+      amax = fmaxf(amax, fabsf(y));
+      e[u] = fminf(fmaxf(y, -65504.f), 65504.f);
+    }
+    const st_f16x2 h = __builtin_convertvector(e, st_f16x2);
+    const st_f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, st_f32x2), st_f16x2);
+    ph[i] = __builtin_bit_cast(unsigned, h);
+    pl[i] = __builtin_bit_cast(unsigned, l);
+  }
+  if (range_flag && !(amax <= 65504.f)) atomicOr(range_flag, 1);
+  uint4* ob = out + ((long long)b * (C / 8) + cg) * 2 * L + t;
+  ob[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+  ob[L] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+}
+
+hipError_t launch_stage_f16x2(const float* x, float* out, int B, int C, int L, float scale, float slope, int* range_flag,
+                              hipStream_t s) {
+  if (B <= 0 || C <= 0 || C % 8 || L <= 0 || B > 65535 || C / 8 > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(stage_f16x2_kernel, dim3((L + 255) / 256, C / 8, B), dim3(256), 0, s, x,
+                     reinterpret_cast<uint4*>(out), C, L, scale, slope, range_flag);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // length regulator (reference models.py:426-455): phoneme p of row b is repeated max(int(dur[b][p]), 0) times.
 // plan: integer durations -> inclusive prefix sum per row (block scan in LDS);  gather: per frame, binary search
 // of the prefix sums, then a coalesced copy of the phoneme's channel vector.

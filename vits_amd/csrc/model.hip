@@ -190,8 +190,9 @@ inline long long staged_row_floats(int prec, int C, int L) { return prec == PREC
 int conv_simple(const ConvDesc& d, const float* x, float* out, int B, int L, const int* lengths, int flags,
                 hipStream_t s, const float* res = nullptr, const float* cbias = nullptr, int cbias_bs = 0,
                 const float* in_cbias = nullptr, int in_cbias_bs = 0, float in_scale = 1.f, float in_slope = 1.f,
-                float out_slope = 1.f) {
+                float out_slope = 1.f, float* out2 = nullptr) {
   ConvArgs a = base_args(x, (long long)d.Cin * L, L, out, (long long)d.cout * L * d.up, L * d.up, B, L, lengths, flags);
+  a.out2 = out2; a.out2_bs = (long long)d.cout * L;          // staged f16x2 copy: as many bytes per element as fp32
   if (flags & F_IN_STAGED) a.x_bs = staged_row_floats(d.prec, d.Cin, L);
   if (flags & F_OUT_STAGED) a.out_bs = staged_row_floats(d.prec, d.cout, L);
   a.out_slope = out_slope;
@@ -834,7 +835,9 @@ static bool fused_pairs_enabled() {
 
 int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec) {
   if (!model_alive(m)) return -1;
-  return (2 + 2 * (int64_t)m->cfg.n_resblock_kernels) * pad256(gen_buf_floats(m, B, t_dec));
+  // x, the sum of the chains, x in staged form; per ResBlock chain: its carrier, the tensor between the two convs of
+  // a pair, the carrier in staged form
+  return (3 + 3 * (int64_t)m->cfg.n_resblock_kernels) * pad256(gen_buf_floats(m, B, t_dec));
 }
 
 int vits_generator(const vits_model* m, const float* z, const int* lengths, const float* cond, int B, int T, int t_dec,
@@ -846,13 +849,14 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
   const int IC = c.inter_channels, ch0 = c.upsample_initial_channel, nk = c.n_resblock_kernels, nd = c.n_resblock_dilations;
   Arena ar(ws, ws_bytes);
   const int64_t nbuf = gen_buf_floats(m, B, t_dec);
-  float *X = ar.take(nbuf), *XS = ar.take(nbuf), *Y[8], *Tt[8];
+  float *X = ar.take(nbuf), *XS = ar.take(nbuf), *XG = ar.take(nbuf), *Y[8], *Tt[8], *YG[8];
   for (int j = 0; j < nk; ++j) {
     Y[j] = ar.take(nbuf);
     Tt[j] = ar.take(nbuf);
-    if (!Y[j] || !Tt[j]) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
+    YG[j] = ar.take(nbuf);
+    if (!Y[j] || !Tt[j] || !YG[j]) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
   }
-  if (!X || !XS) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
+  if (!X || !XS || !XG) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
   // per-kernel event timing needs the launches of one step serialised on one stream
   const int n_side = prof_enabled() ? 0 : std::max(0, std::min(m->n_side, m->side_limit));
   RangeFlagScope range_scope(m->range_flag);
@@ -872,6 +876,18 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
     // The nk ResBlocks read the same x and are independent until their outputs are summed (models.py:292-298):
     // chain j runs on its own stream; its last conv accumulates into XS after chain j-1's has (same order of
     // additions as the reference: (rb0 + rb1) + rb2).
+    // f16x2 arithmetic: every conv of an unfused pair takes its input in the staged operand format (leaky-relu applied,
+    // split into fp16 h / l) -- x is converted once for all chains here, and the second conv of a pair writes its
+    // result twice, as fp32 (the residual of the next pair) and staged (the input of the next pair's first conv).
+    bool stage_x = false;
+    for (int j = 0; j < nk && staged_pairs_enabled(); ++j) {
+      const ResBlock& rb = m->rbs[i * nk + j];
+      bool fused = fused_pairs_enabled();
+      for (int q = 0; q < nd && fused; ++q) fused = pair_profitable(rb.c1[q], rb.c2[q]);
+      if (!fused && rb.c1[0].prec == PREC_F16X2 && rb.c2[0].prec == PREC_F16X2) stage_x = true;
+    }
+    if (stage_x)
+      HIP_TRY(launch_stage_f16x2(X, XG, B, m->rbs[i * nk].c1[0].Cin, L, 1.f, 0.1f, g_range_flag, s));
     if (n_side > 0) {
       HIP_TRY(hipEventRecord(m->ev_fork, s));
       for (int j = 0; j < n_side; ++j) HIP_TRY(hipStreamWaitEvent(m->side[j], m->ev_fork, 0));
@@ -907,13 +923,17 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
         // staging; half the bytes in bf16 mode).
         const int p1 = rb.c1[q].prec;
         const bool staged = staged_pairs_enabled() && p1 == rb.c2[q].prec && (p1 == PREC_BF16 || p1 == PREC_F16X2);
-        TRY(conv_simple(rb.c1[q], yin, Tt[j], B, L, nullptr, F_IN_LRELU | (staged ? F_OUT_STAGED : 0), sj, nullptr, nullptr,
-                        0, nullptr, 0, 1.f, 0.1f, 0.1f));
+        const bool staged_in = staged && p1 == PREC_F16X2 && stage_x;      // the first conv's input is staged as well
+        const float* c1_in = staged_in ? (q == 0 ? XG : YG[j]) : yin;
+        TRY(conv_simple(rb.c1[q], c1_in, Tt[j], B, L, nullptr,
+                        (staged_in ? F_IN_STAGED : F_IN_LRELU) | (staged ? F_OUT_STAGED : 0), sj, nullptr, nullptr, 0,
+                        nullptr, 0, 1.f, 0.1f, 0.1f));
         const bool last = q + 1 == nd;
         float* dst = last ? XS : Y[j];
         const int flags = (staged ? F_IN_STAGED : F_IN_LRELU) | F_RES | (last && j > 0 ? F_ACCUM : 0);
         if (last && j > 0 && n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
-        TRY(conv_simple(rb.c2[q], Tt[j], dst, B, L, nullptr, flags, sj, yin, nullptr, 0, nullptr, 0, 1.f, 0.1f));
+        TRY(conv_simple(rb.c2[q], Tt[j], dst, B, L, nullptr, flags, sj, yin, nullptr, 0, nullptr, 0, 1.f, 0.1f, 0.1f,
+                        staged_in && !last ? YG[j] : nullptr));
         yin = Y[j];
       }
       if (n_side > 0) HIP_TRY(hipEventRecord(m->ev_done[j], sj));
