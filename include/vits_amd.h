@@ -133,6 +133,16 @@ int64_t vits_flow_workspace_bytes(const vits_model* m, int B, int T);
 int vits_flow_reverse(const vits_model* m, float* z, const int* frame_lengths, const float* cond, int B, int T,
                       void* ws, int64_t ws_bytes, void* stream);
 
+/* vits_flow_reverse for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): the same kernels and results, with the three work tensors in a fixed
+ * 18 MiB array inside the library's device image instead of a caller workspace.  It has no counterpart in the
+ * reference.  Limit: B * T <= vits_flow_noalloc_max_positions() (8192) and hidden_channels <= 192; beyond it the call
+ * fails with VITS_ERR_WORKSPACE.  It calls no allocating routine.  Every call on one GPU uses that GPU's single copy
+ * of the array: calls that overlap on one GPU (different streams or threads) race. */
+int64_t vits_flow_noalloc_max_positions(void);
+int vits_flow_reverse_noalloc(const vits_model* m, float* z, const int* frame_lengths, const float* cond, int B, int T,
+                              void* stream);
+
 /* ResidualCouplingBlock.forward(reverse=False) (reference models.py:209-212, modules.py:320-335) in place on z: the
  * z -> z_p direction used by voice conversion (models.py:774).  Same workspace as vits_flow_reverse. */
 int vits_flow_forward(const vits_model* m, float* z, const int* frame_lengths, const float* cond, int B, int T,

@@ -69,6 +69,8 @@ def _load():
         "vits_flow_workspace_bytes": (i64, [vp, i32, i32]),
         "vits_flow_reverse": (i32, [vp, vp, vp, vp, i32, i32, vp, i64, vp]),
         "vits_flow_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, i64, vp]),
+        "vits_flow_noalloc_max_positions": (i64, []),
+        "vits_flow_reverse_noalloc": (i32, [vp, vp, vp, vp, i32, i32, vp]),
         "vits_posterior_channels": (i32, [vp]),
         "vits_posterior_workspace_bytes": (i64, [vp, i32, i32]),
         "vits_posterior_encoder": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),

@@ -768,6 +768,55 @@ int vits_flow_reverse(const vits_model* m, float* z, const int* lengths, const f
   return run_flow(m, z, lengths, cond, B, T, ws, ws_bytes, (hipStream_t)stream, true);
 }
 
+// ---- vits_flow_reverse for callers that cannot allocate ----
+// The coupling block's three work tensors (h, gate output, skip sum; 3 * B * hidden * T floats) live in a fixed array
+// in the library's device image instead of a caller workspace.  Every GPU the library runs on holds its own copy of
+// the array at its own address for the life of the process; host code never uses the array's name as an address
+// (it is only a host-side stand-in), it uses the per-device pointer hipGetSymbolAddress returned.
+#define VITS_NOALLOC_MAX_POSITIONS 8192      /* B * T */
+#define VITS_NOALLOC_MAX_HIDDEN 192
+constexpr int64_t kFlowScratchBytes = 3 * (int64_t)VITS_NOALLOC_MAX_POSITIONS * VITS_NOALLOC_MAX_HIDDEN * 4;   // 18 MiB
+static __device__ __align__(256) __attribute__((used)) unsigned char g_flow_scratch[kFlowScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_flow_scratch_ptr[kMaxDevices] = {};
+
+// Address of the current device's copy of g_flow_scratch (resolved once per device, with that device current).
+int flow_scratch_for_current_device(void** out) {
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(VITS_ERR_INVALID, "flow_reverse_noalloc: device index out of range");
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_flow_scratch_ptr[dev]) {
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_flow_scratch)));
+    if (!p) return fail(VITS_ERR_HIP, "hipGetSymbolAddress returned a null address for the flow scratch");
+    g_flow_scratch_ptr[dev] = p;
+  }
+  *out = g_flow_scratch_ptr[dev];
+  return VITS_OK;
+}
+}  // namespace
+
+int64_t vits_flow_noalloc_max_positions(void) { return VITS_NOALLOC_MAX_POSITIONS; }
+
+int vits_flow_reverse_noalloc(const vits_model* m, float* z, const int* lengths, const float* cond, int B, int T,
+                              void* stream) {
+  CHECK_MODEL(m);
+  if (B <= 0 || T <= 0) return fail(VITS_ERR_INVALID, "flow_reverse_noalloc: B and T must be positive");
+  if (m->cfg.hidden_channels > VITS_NOALLOC_MAX_HIDDEN || (int64_t)B * T > VITS_NOALLOC_MAX_POSITIONS ||
+      vits_flow_workspace_bytes(m, B, T) > kFlowScratchBytes)
+    return fail(VITS_ERR_WORKSPACE, "flow_reverse_noalloc: B * T exceeds 8192 positions (or hidden_channels 192), the "
+                                    "size of the library's fixed scratch; use vits_flow_reverse with a workspace");
+  void* scratch = nullptr;
+  TRY(flow_scratch_for_current_device(&scratch));
+  // nothing in the scratch has to start at zero: h, the gate output and the skip sum are each written in full
+  // (every row, every t < T of every batch row) before they are read
+  return run_flow(m, z, lengths, cond, B, T, scratch, kFlowScratchBytes, (hipStream_t)stream, true);
+}
+
 void vits_op_set_range_flag(int* dev_flag) { g_range_flag = dev_flag; }
 
 int vits_flow_forward(const vits_model* m, float* z, const int* lengths, const float* cond, int B, int T, void* ws,
