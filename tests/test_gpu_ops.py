@@ -338,8 +338,10 @@ def reference_attention(q, k, v, ek, ev, lengths, H, W=4):
     return out.transpose(2, 3).reshape(B, C, L)
 
 
-@pytest.mark.parametrize("L", [3, 12, 50, 130, 258, 600])
+@pytest.mark.parametrize("L", [3, 12, 50, 130, 255, 256, 258, 600, 861, 1400])
 def test_attention(N, L):
+    """L < 256: the lanes-on-keys kernel; L >= 256: the matrix-core kernel (bf16x3 products, two passes over the keys).
+    Both against the reference's own formulation (padded relative embeddings, skew reshapes)."""
     g = torch.Generator().manual_seed(L)
     B, H, dk = 2, 2, 96
     C = H * dk

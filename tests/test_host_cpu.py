@@ -145,11 +145,11 @@ def test_polyphase_rows_match_conv_transpose1d(u, k, cin, cout):
 def test_prepare_covers_every_used_key(synthetic_sd):
     cfg = synthetic.ModelConfig()
     pw = weights.prepare(synthetic_sd, cfg)
-    base = 14 * 4 + 2 + 2 + 1 + 4 * (2 + 4 + 3 + 4) + 1 + 4 + 72
+    base = 14 * 4 + 2 + 2 + 1 + 4 * (2 + 4 + 3 + 4 + 3) + 1 + 4 + 72     # per flow: pre, post, 4 in, 3 res, 4 skip, 3 res+skip
     no_q = {k: v for k, v in synthetic_sd.items() if not k.startswith("enc_q.")}
     assert len(weights.prepare(no_q, cfg).convs) == base
     # with the posterior encoder's weights: pre, proj, 16 gated convs, 15 res + 16 skip 1x1 convs, 6144 cond rows
-    assert "enc_q.pre.weight" in synthetic_sd and len(pw.convs) == base + 2 + 16 + 15 + 16
+    assert "enc_q.pre.weight" in synthetic_sd and len(pw.convs) == base + 2 + 16 + 15 + 16 + 15
     assert pw.convs["enc_q.pre"][2:5] == (1040, 192, 1)
     flow0 = pw.convs["flow.0.in.0"]
     assert flow0[2:] == (192, 384, 5, 1, N.MODE_GATE, N.PREC_F32)

@@ -76,6 +76,11 @@ struct ConvArgs {
   float in_scale, in_slope;
   float out_slope;                                   // F_OUT_STAGED: leaky-relu slope the consumer would apply
   int toff0[2], tstep[2];                            // tap k reads x[t + toff0 + k * tstep] (per row class)
+  // MODE_PLAIN, optional second destination: rows >= split_row (a multiple of 64; 0 = off) go to out_hi (row
+  // split_row is its row 0) under flags_hi, with no residual; rows below it to out / res under flags.  One launch then
+  // serves WaveNet's res_skip conv: the residual half updates x, the skip half accumulates into the skip sum.
+  int split_row; int flags_hi;
+  float* out_hi; long long out_hi_bs;
   float* out2; long long out2_bs;                    // MODE_PLAIN, optional: a second copy of the result in the staged
                                                      // f16x2 format (leaky-relu(out_slope) applied), for the next conv
   int* range_flag;                                   // PREC_F16X2: OR 1 into *range_flag when an activation lies outside

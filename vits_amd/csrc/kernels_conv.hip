@@ -150,6 +150,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
   float* out_b = a.out + (long long)b * a.out_bs;
   if constexpr (MODE == MODE_PLAIN) {
     const float* res_b = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+    int flags = a.flags;
+    if (a.split_row > 0 && mt[0] * 32 >= a.split_row) {      // the wave's rows belong to the second destination
+      out_b = a.out_hi + (long long)b * a.out_hi_bs - (long long)a.split_row * a.out_cs;
+      flags = a.flags_hi;
+      res_b = nullptr;
+    }
     // Residual loads go out before the first store of the rows they cover (out may alias res element for element,
     // which this order keeps correct).  RES_ALL: the whole wave tile at once (one memory round trip, WM * WN * 16
     // registers); otherwise one 32-row block at a time.
@@ -166,7 +172,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
       }
     };
     if constexpr (RES_ALL) {
-      if (a.flags & (F_RES | F_RES_SUB)) {
+      if (flags & (F_RES | F_RES_SUB)) {
 #pragma unroll
         for (int i = 0; i < WM; ++i) load_res(i, i);
       }
@@ -177,7 +183,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
       const int rowu = mt[i] * 32;
       const int ri = RES_ALL ? i : 0;
       if constexpr (!RES_ALL) {
-        if (a.flags & (F_RES | F_RES_SUB)) load_res(i, 0);
+        if (flags & (F_RES | F_RES_SUB)) load_res(i, 0);
       }
       float bz[16];                        // whole-array branches: the 16 loads of a table are issued back to back
       const int row0 = rowu + 4 * par;
@@ -202,7 +208,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
           const float m = t < len_b ? 1.f : 0.f;
           const unsigned lo_out = (unsigned)(4 * par * a.out_cs + t);
           float ov[16];
-          if (a.flags & F_ACCUM) {
+          if (flags & F_ACCUM) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               ov[r] = (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out];
@@ -211,12 +217,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[i][j][r] + bz[r];
-            if (a.flags & F_RELU) v = fmaxf(v, 0.f);
-            if (a.flags & F_MASK_PRE) v *= m;
-            if (a.flags & F_RES) v += rv[ri][j][r];
-            if (a.flags & F_RES_SUB) v = rv[ri][j][r] - v;
-            if (a.flags & F_ACCUM) v += ov[r];
-            if (a.flags & F_MASK_POST) v *= m;
+            if (flags & F_RELU) v = fmaxf(v, 0.f);
+            if (flags & F_MASK_PRE) v *= m;
+            if (flags & F_RES) v += rv[ri][j][r];
+            if (flags & F_RES_SUB) v = rv[ri][j][r] - v;
+            if (flags & F_ACCUM) v += ov[r];
+            if (flags & F_MASK_POST) v *= m;
             fv[r] = v;
             (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = v;
           }
@@ -2010,6 +2016,9 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   if ((a.flags & F_OUT_STAGED) && (a.flags & (F_RELU | F_MASK_PRE | F_RES | F_RES_SUB | F_ACCUM | F_MASK_POST)))
     return hipErrorInvalidValue;
   if ((a.flags & (F_IN_STAGED | F_OUT_STAGED)) && (d.Cin % 16 || M % 32)) return hipErrorInvalidValue;
+  if (a.split_row && (d.mode != MODE_PLAIN || a.split_row % 64 || a.split_row >= M || !a.out_hi || a.out2 ||
+                      (a.flags & (F_OUT_STAGED | F_IN_STAGED)) || ((a.flags | a.flags_hi) & F_RES_SUB)))
+    return hipErrorInvalidValue;
   if (a.out2 && (d.mode != MODE_PLAIN || p != PREC_F16X2 || (a.flags & F_OUT_STAGED))) return hipErrorInvalidValue;
   if (p == PREC_BF16X3 && (d.mode == MODE_PLAIN || d.mode == MODE_GATE)) {
     hipError_t err = hipSuccess;

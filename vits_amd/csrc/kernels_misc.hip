@@ -4,6 +4,7 @@
 // contiguous axis of the [B, C, L] layout, so global accesses are coalesced.
 #include "common.h"
 #include <math.h>
+#include <cstdlib>
 
 namespace vits {
 
@@ -260,9 +261,335 @@ static void attention_launch(const float* qkv, const float* emb_k, const float* 
   hipLaunchKernelGGL((attention_kernel<NCH, QPW>), grid, dim3(256), lds, s, qkv, emb_k, emb_v, lengths, out, H, L);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same attention on the matrix cores, for long sequences (L >= 256).
+//   S'[j][i] = k_j . q_i  (keys x queries: the transposed score tile), v_mfma_f32_32x32x16_bf16 with every fp32 operand
+//   split exactly into three bf16 terms and the six largest cross products (fp32-grade, as the bf16x3 convs);
+//   O[c][i]  = sum_j v[c][j] p[j][i]: the 32 x 32 accumulator layout of S' (a lane holds one query column and, per
+//   register, keys 8g + 4*par + q) is used as the B operand of this product as it stands -- the sum over keys does not
+//   care in which order its terms sit in the MFMA's k slots, so V is staged in that same key order instead of the
+//   probabilities being shuffled across lanes.
+// A block of NW waves owns 32 * NW queries of one (batch, head); keys and values pass through LDS in tiles of 64,
+// split into bf16 planes once per block.  Two passes over the keys: the row maximum first, then exp, row sum and p . v
+// (no rescaling of partial results).  The +-4 relative-position terms: q . Ek through one more MFMA tile (the nine
+// embeddings as nine "keys"), added to the scores inside the band; the band's probabilities are collected per query
+// and multiplied with Ev as one last k step of the p . v product.
+// ---------------------------------------------------------------------------------------------------------
+typedef float att_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 att_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 att_bf16x2 __attribute__((ext_vector_type(2)));
+
+// (v0, v1) -> packed bf16 pairs h, m, l with v = h + m + l exactly (low half = v0)
+__device__ __forceinline__ void att_split3(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+  const att_f32x2 v = {v0, v1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, att_bf16x2));
+  const att_f32x2 r1 = {v0 - __builtin_bit_cast(float, h << 16), v1 - __builtin_bit_cast(float, h & 0xffff0000u)};
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, att_bf16x2));
+  const att_f32x2 r2 = {r1.x - __builtin_bit_cast(float, m << 16), r1.y - __builtin_bit_cast(float, m & 0xffff0000u)};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, att_bf16x2));
+}
+
+// eight fp32 values -> one 16-byte unit per plane
+__device__ __forceinline__ void att_split3_unit(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
+  unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) att_split3(v[2 * e], v[2 * e + 1], ph[e], pm[e], pl[e]);
+  h = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+  m = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+  l = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+}
+
+__device__ __forceinline__ att_f32x16 att_mma(const uint4& a, const uint4& b, att_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a), __builtin_bit_cast(att_bf16x8, b), c, 0,
+                                                 0, 0);
+}
+
+// six cross products of two three-plane operands, smallest first: a_h b_l, a_h b_m, a_m b_m, a_l b_h, a_m b_h, a_h b_h
+__device__ __forceinline__ att_f32x16 att_mma6(const uint4 (&a)[3], const uint4 (&b)[3], att_f32x16 c) {
+  c = att_mma(a[0], b[2], c);
+  c = att_mma(a[2], b[0], c);
+  c = att_mma(a[1], b[1], c);
+  c = att_mma(a[0], b[1], c);
+  c = att_mma(a[1], b[0], c);
+  c = att_mma(a[0], b[0], c);
+  return c;
+}
+
+constexpr int ATT_KT = 64;                         // keys per LDS tile
+constexpr int ATT_NCG = ATT_DK / 8;                // 16-byte channel groups per head (12)
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ ek,
+                                                                  const float* __restrict__ ev,
+                                                                  const int* __restrict__ lengths, float* __restrict__ out,
+                                                                  int H, int L) {
+  constexpr int DK = ATT_DK, W = ATT_W, NR = 2 * ATT_W + 1, NQ = 32 * NW, NT = 64 * NW, NCG = ATT_NCG;
+  constexpr int KQ_UNITS = 3 * NCG * ATT_KT;       // K tile: [3 planes][12 groups][64 keys]
+  constexpr int VQ_UNITS = 3 * DK * 8;             // V tile: [3 planes][96 channels][4 k steps x 2 halves], keys permuted
+  extern __shared__ __attribute__((aligned(16))) uint4 att_m[];
+  uint4* kq = att_m;
+  uint4* vq = att_m + KQ_UNITS;
+  uint4* evq = vq + VQ_UNITS;                      // Ev as one k step of V: [3 planes][96 channels][2 halves]
+  float* qe_s = reinterpret_cast<float*>(evq + 3 * DK * 2);     // [NQ][NR]   q . Ek
+  float* pw_s = qe_s + NQ * NR;                    // [NQ][NR]   band probabilities (unnormalised)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int par = lane >> 5, l31 = lane & 31;
+  const int i0 = blockIdx.x * NQ, h = blockIdx.y, b = blockIdx.z;
+  const int C = H * DK;
+  const int len = lengths ? lengths[b] : L;
+  const float* qb = qkv + ((long long)b * 3 * C + h * DK) * L;
+  const float* kb = qb + (long long)C * L;
+  const float* vb = kb + (long long)C * L;
+  const float qscale = 1.f / sqrtf((float)DK);
+  const int il = 32 * wave + l31;                  // this lane's query inside the block
+  const int iq = i0 + il;
+
+  // ---- Q: staged (scaled, split) through the K / V tile space, then held in registers as B fragments ----
+  for (int u = tid; u < NCG * NQ; u += NT) {
+    const int cg = u / NQ, i = u % NQ;
+    const int ii = i0 + i < L ? i0 + i : L - 1;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = qb[(long long)(8 * cg + e) * L + ii] * qscale;
+    att_split3_unit(v, att_m[(0 * NCG + cg) * NQ + i], att_m[(1 * NCG + cg) * NQ + i], att_m[(2 * NCG + cg) * NQ + i]);
+  }
+  for (int idx = tid; idx < NQ * NR; idx += NT) pw_s[idx] = 0.f;
+  __syncthreads();
+  uint4 Qf[6][3];                                  // [k step of 16 channels][plane]
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) Qf[ks][p] = att_m[(p * NCG + 2 * ks + par) * NQ + il];
+  __syncthreads();
+
+  // ---- Ek as a 32-"key" tile (rows >= 9 zero) for q . Ek; Ev as one k step of values ----
+  for (int u = tid; u < NCG * 32; u += NT) {
+    const int cg = u / 32, r = u % 32;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = r < NR ? ek[r * DK + 8 * cg + e] : 0.f;
+    att_split3_unit(v, kq[(0 * NCG + cg) * ATT_KT + r], kq[(1 * NCG + cg) * ATT_KT + r], kq[(2 * NCG + cg) * ATT_KT + r]);
+  }
+  for (int u = tid; u < DK * 2; u += NT) {
+    const int c = u >> 1, hp = u & 1;              // k slot e of half hp <-> embedding row 8 * (e >> 2) + 4 * hp + (e & 3)
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * (e >> 2) + 4 * hp + (e & 3);
+      v[e] = r < NR ? ev[r * DK + c] : 0.f;
+    }
+    att_split3_unit(v, evq[(0 * DK + c) * 2 + hp], evq[(1 * DK + c) * 2 + hp], evq[(2 * DK + c) * 2 + hp]);
+  }
+  __syncthreads();
+  {
+    att_f32x16 e;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+      uint4 a[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[p] = kq[(p * NCG + 2 * ks + par) * ATT_KT + l31];
+      e = att_mma6(a, Qf[ks], e);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rel = 8 * (r >> 2) + 4 * par + (r & 3);
+      if (rel < NR) qe_s[il * NR + rel] = e[r];
+    }
+  }
+
+  auto stage_k = [&](int jb) __attribute__((always_inline)) {
+    for (int u = tid; u < NCG * ATT_KT; u += NT) {
+      const int cg = u / ATT_KT, j = u % ATT_KT;
+      const bool ok = jb + j < L;
+      const float* kp = kb + (long long)(8 * cg) * L + (ok ? jb + j : L - 1);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = kp[(long long)e * L];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ok ? v[e] : 0.f;
+      att_split3_unit(v, kq[(0 * NCG + cg) * ATT_KT + j], kq[(1 * NCG + cg) * ATT_KT + j], kq[(2 * NCG + cg) * ATT_KT + j]);
+    }
+  };
+  auto stage_v = [&](int jb) __attribute__((always_inline)) {
+    for (int u = tid; u < DK * 8; u += NT) {
+      const int c = u >> 3, s8 = u & 7;            // s8 = 2 * (k step of 16 keys) + half
+      const int k0 = jb + 16 * (s8 >> 1) + 4 * (s8 & 1);
+      const float* vp = vb + (long long)c * L;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = k0 + 8 * (e >> 2) + (e & 3);
+        v[e] = vp[j < L ? j : L - 1];
+        v[e] = j < L ? v[e] : 0.f;
+      }
+      att_split3_unit(v, vq[(0 * DK + c) * 8 + s8], vq[(1 * DK + c) * 8 + s8], vq[(2 * DK + c) * 8 + s8]);
+    }
+  };
+  // S' of the staged key tile for this wave's 32 queries, relative-position term and masking applied
+  auto scores = [&](int jb, att_f32x16 (&sc)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[mt][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        uint4 a[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = kq[(p * NCG + 2 * ks + par) * ATT_KT + 32 * mt + l31];
+        sc[mt] = att_mma6(a, Qf[ks], sc[mt]);
+      }
+    // the band |j - i| <= W touches this tile only when the tile's keys come near the wave's queries
+    const int wq0 = i0 + 32 * wave;
+    const bool near = jb <= wq0 + 31 + W && jb + ATT_KT - 1 >= wq0 - W;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = jb + 32 * mt + 8 * (r >> 2) + 4 * par + (r & 3);
+        float v = sc[mt][r];
+        if (near) {
+          const int d = j - iq + W;
+          if (d >= 0 && d < NR) v += qe_s[il * NR + d];
+        }
+        if (!(iq < len && j < len)) v = -1e4f;
+        sc[mt][r] = j < L ? v : -INFINITY;
+      }
+  };
+
+  // ---- pass 1: row maxima ----
+  float mx = -INFINITY;
+  for (int jb = 0; jb < L; jb += ATT_KT) {
+    __syncthreads();
+    stage_k(jb);
+    __syncthreads();
+    att_f32x16 sc[2];
+    scores(jb, sc);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[mt][r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+
+  // ---- pass 2: p = exp(s - max), row sums, p . v ----
+  att_f32x16 o[3];
+#pragma unroll
+  for (int mc = 0; mc < 3; ++mc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[mc][r] = 0.f;
+  float lsum = 0.f;
+  for (int jb = 0; jb < L; jb += ATT_KT) {
+    __syncthreads();
+    stage_k(jb);
+    stage_v(jb);
+    __syncthreads();
+    att_f32x16 sc[2];
+    scores(jb, sc);
+    const int wq0 = i0 + 32 * wave;
+    const bool near = jb <= wq0 + 31 + W && jb + ATT_KT - 1 >= wq0 - W;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = expf(sc[mt][r] - mx);      // exp(-inf) = 0 for keys beyond L
+        sc[mt][r] = p;
+        lsum += p;
+        if (near) {
+          const int j = jb + 32 * mt + 8 * (r >> 2) + 4 * par + (r & 3);
+          const int d = j - iq + W;
+          if (d >= 0 && d < NR && j < L) pw_s[il * NR + d] = p;
+        }
+      }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = sc[mt][8 * hh + e];
+        uint4 pb[3];
+        att_split3_unit(pv, pb[0], pb[1], pb[2]);
+        const int s8 = 2 * (2 * mt + hh) + par;
+#pragma unroll
+        for (int mc = 0; mc < 3; ++mc) {
+          uint4 a[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) a[p] = vq[(p * DK + 32 * mc + l31) * 8 + s8];
+          o[mc] = att_mma6(a, pb, o[mc]);
+        }
+      }
+  }
+  lsum += __shfl_xor(lsum, 32);
+  // ---- the band's probabilities times Ev: one more k step (LDS accesses of one wave complete in order, and pw_s rows
+  // are written and read by the two lanes of the same query only) ----
+  {
+    float pv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * (e >> 2) + 4 * par + (e & 3);
+      pv[e] = r < NR ? pw_s[il * NR + r] : 0.f;
+    }
+    uint4 pb[3];
+    att_split3_unit(pv, pb[0], pb[1], pb[2]);
+#pragma unroll
+    for (int mc = 0; mc < 3; ++mc) {
+      uint4 a[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[p] = evq[(p * DK + 32 * mc + l31) * 2 + par];
+      o[mc] = att_mma6(a, pb, o[mc]);
+    }
+  }
+  if (iq < L) {
+    const float rinv = 1.f / lsum;
+    float* ob = out + ((long long)b * C + h * DK) * L + iq;
+#pragma unroll
+    for (int mc = 0; mc < 3; ++mc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ob[(long long)(32 * mc + 4 * par + (r & 3) + 8 * (r >> 2)) * L] = o[mc][r] * rinv;
+  }
+}
+
+template <int NW>
+static void attention_mfma_launch(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
+                                  int B, int H, int L, hipStream_t s) {
+  constexpr int NQ = 32 * NW;
+  const size_t lds = (size_t)(3 * ATT_NCG * ATT_KT + 3 * ATT_DK * 8 + 3 * ATT_DK * 2) * sizeof(uint4) +
+                     (size_t)2 * NQ * (2 * ATT_W + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel<NW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attention_mfma_kernel<NW>), dim3((L + NQ - 1) / NQ, H, B), dim3(64 * NW), lds, s, qkv, emb_k, emb_v,
+                     lengths, out, H, L);
+}
+
+// VITS_ATT_MFMA: the shortest sequence that takes the matrix-core kernel (default 256; 0 = never).
+static int att_mfma_min_len() {
+  static const int n = [] {
+    const char* e = getenv("VITS_ATT_MFMA");
+    return e && e[0] ? atoi(e) : 256;
+  }();
+  return n;
+}
+
 hipError_t launch_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
                             int B, int H, int DK, int L, int window, hipStream_t s) {
   if (DK != ATT_DK || window != ATT_W || B <= 0 || L <= 0 || L > 2048 || B > 65535) return hipErrorInvalidValue;
+  if (att_mfma_min_len() > 0 && L >= att_mfma_min_len()) {
+    // 128 queries a block when that still gives every CU two blocks, else 64
+    if ((long long)((L + 127) / 128) * H * B >= 2LL * device_cu_count())
+      attention_mfma_launch<4>(qkv, emb_k, emb_v, lengths, out, B, H, L, s);
+    else
+      attention_mfma_launch<2>(qkv, emb_k, emb_v, lengths, out, B, H, L, s);
+    return hipGetLastError();
+  }
   const int nch = (L + 63) / 64;
 #define ATT_LAUNCH(N, Q) attention_launch<N, Q>(qkv, emb_k, emb_v, lengths, out, B, H, L, s)
   // The score row lives in registers: QPW * NCH floats per lane, so longer rows take fewer queries per wave.

@@ -67,6 +67,7 @@ struct EncLayer {
 struct FlowLayer {
   ConvDesc pre, post;
   std::vector<ConvDesc> in, res, skip;
+  std::vector<ConvDesc> rs;      // res and skip halves as one conv of 2C rows (when registered): one launch per layer
 };
 
 struct ResBlock {
@@ -385,6 +386,8 @@ int vits_model_finalize(vits_model* m) {
     for (int l = 0; l < nlq; ++l) {
       m->encq.in.push_back(need_conv(m, "enc_q.in." + std::to_string(l), C, 2 * C, c.flow_kernel, MODE_GATE, miss));
       if (l + 1 < nlq) m->encq.res.push_back(need_conv(m, "enc_q.res." + std::to_string(l), C, C, 1, MODE_PLAIN, miss));
+      if (l + 1 < nlq && m->convs.count("enc_q.rs." + std::to_string(l)))
+        m->encq.rs.push_back(need_conv(m, "enc_q.rs." + std::to_string(l), C, 2 * C, 1, MODE_PLAIN, miss));
       m->encq.skip.push_back(need_conv(m, "enc_q.skip." + std::to_string(l), C, C, 1, MODE_PLAIN, miss));
     }
     m->off_encq = m->cond_rows;
@@ -435,6 +438,8 @@ int vits_model_finalize(vits_model* m) {
     for (int l = 0; l < c.flow_layers; ++l) {
       fl.in.push_back(need_conv(m, p + ".in." + std::to_string(l), C, 2 * C, c.flow_kernel, MODE_GATE, miss));
       if (l + 1 < c.flow_layers) fl.res.push_back(need_conv(m, p + ".res." + std::to_string(l), C, C, 1, MODE_PLAIN, miss));
+      if (l + 1 < c.flow_layers && m->convs.count(p + ".rs." + std::to_string(l)))
+        fl.rs.push_back(need_conv(m, p + ".rs." + std::to_string(l), C, 2 * C, 1, MODE_PLAIN, miss));
       fl.skip.push_back(need_conv(m, p + ".skip." + std::to_string(l), C, C, 1, MODE_PLAIN, miss));
     }
     m->flows.push_back(fl);
@@ -708,6 +713,15 @@ int64_t vits_flow_workspace_bytes(const vits_model* m, int B, int T) {
   return 3 * pad256((int64_t)B * m->cfg.hidden_channels * T);
 }
 
+// VITS_WN_RS=0 keeps WaveNet's res and skip 1x1 convs as two launches (A/B measurements).
+static bool res_skip_one_launch() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_WN_RS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 // modules.WN.forward (reference modules.py:144-172) on h (updated in place), result in `skip`: per layer the gated conv
 // with its slice of the conditioning, then the 1x1 res / skip convs (the reference's single res_skip conv, split).
 static int run_wn(const FlowLayer& wn, float* h, float* acts, float* skip, const float* cf, int cr, int C, int B, int T,
@@ -715,7 +729,13 @@ static int run_wn(const FlowLayer& wn, float* h, float* acts, float* skip, const
   const int NL = (int)wn.in.size();
   for (int l = 0; l < NL; ++l) {
     TRY(conv_simple(wn.in[l], h, acts, B, T, lengths, 0, s, nullptr, cf + (long long)l * 2 * C, cr));
-    if (l + 1 < NL) {
+    if (l + 1 < NL && (int)wn.rs.size() == NL - 1 && C % 64 == 0 && res_skip_one_launch()) {
+      // the reference's single res_skip conv (modules.py:164-170): rows [0, C) update x, rows [C, 2C) go to the skip sum
+      ConvArgs a = base_args(acts, (long long)C * T, T, h, (long long)C * T, T, B, T, lengths, F_RES | F_MASK_POST);
+      a.res = h; a.res_bs = (long long)C * T; a.res_cs = T;
+      a.split_row = C; a.out_hi = skip; a.out_hi_bs = (long long)C * T; a.flags_hi = l ? F_ACCUM : 0;
+      HIP_TRY(launch_conv(wn.rs[l], a, s));
+    } else if (l + 1 < NL) {
       TRY(conv_simple(wn.res[l], acts, h, B, T, lengths, F_RES | F_MASK_POST, s, h));
       TRY(conv_simple(wn.skip[l], acts, skip, B, T, lengths, l ? F_ACCUM : 0, s));
     } else {

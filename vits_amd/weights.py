@@ -209,6 +209,7 @@ def prepare(sd: Dict[str, torch.Tensor], cfg, precision: int = N.PREC_F32) -> Pr
             if l + 1 < nl:
                 pw.add_conv(f"{o}.res.{l}", w_rs[:C], b_rs[:C])
                 pw.add_conv(f"{o}.skip.{l}", w_rs[C:], b_rs[C:])
+                pw.add_conv(f"{o}.rs.{l}", w_rs, b_rs)        # both halves as the reference's single conv: one launch
             else:
                 pw.add_conv(f"{o}.skip.{l}", w_rs, b_rs)
         cw.append(folded(sd, p + ".enc.cond_layer")[:, :, 0])
@@ -229,6 +230,7 @@ def prepare(sd: Dict[str, torch.Tensor], cfg, precision: int = N.PREC_F32) -> Pr
             if l + 1 < nlq:
                 pw.add_conv(f"enc_q.res.{l}", w_rs[:C], b_rs[:C])
                 pw.add_conv(f"enc_q.skip.{l}", w_rs[C:], b_rs[C:])
+                pw.add_conv(f"enc_q.rs.{l}", w_rs, b_rs)
             else:
                 pw.add_conv(f"enc_q.skip.{l}", w_rs, b_rs)
         cw.append(folded(sd, "enc_q.enc.cond_layer")[:, :, 0])
