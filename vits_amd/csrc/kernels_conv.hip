@@ -1578,7 +1578,7 @@ static hipError_t launch_gl_cfg(ConvArgs& a, hipStream_t stream) {
   }
   dim3 grid((a.L + BN - 1) / BN, a.M / BM, a.B);
   char name[96];
-  snprintf(name, sizeof name, "conv_gl_kernel<%d,%d,%d,%d>", WN, WGM, WGN, K);
+  snprintf(name, sizeof name, "conv_gl_kernel<%d,%d,%d,%d,%d,%d>", WN, WGM, WGN, K, D, A);
   return timed_launch(name, false, a, stream, [&] {
     hipLaunchKernelGGL((conv_gl_kernel<WN, WGM, WGN, K, D, A>), grid, dim3(256), lds, stream, a);
   });
@@ -1607,7 +1607,11 @@ static bool try_launch_gl(ConvArgs& a, hipStream_t stream, hipError_t& err) {
   // 128 x 256 tiles when that still gives every slot a block, else 128 x 128; a grid that cannot even give every CU a
   // block stays with the register-ring variant of the other kernel (batch-1 latency)
   const bool wide = tall && gl_wide() && blocks_of(256) > slots;
-  if (blocks_of(wide || !tall ? 256 : 128) <= slots / 2) return false;
+  static const long long min_blocks = [] {
+    const char* e = getenv("VITS_CONV_GL_MIN_BLOCKS");
+    return e && e[0] ? atoll(e) : -1LL;
+  }();
+  if (blocks_of(wide || !tall ? 256 : 128) <= (min_blocks >= 0 ? min_blocks : slots / 2)) return false;
   // look-ahead D steps; the activation tile goes out A chunks ahead with A * K >= D
   if (wide)
     err = a.K == 3 ? launch_gl_cfg<4, 2, 2, 3, 3, 1>(a, stream) : a.K == 7 ? launch_gl_cfg<4, 2, 2, 7, 3, 1>(a, stream)

@@ -582,7 +582,11 @@ static int att_mfma_min_len() {
 hipError_t launch_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
                             int B, int H, int DK, int L, int window, hipStream_t s) {
   if (DK != ATT_DK || window != ATT_W || B <= 0 || L <= 0 || L > 2048 || B > 65535) return hipErrorInvalidValue;
-  if (att_mfma_min_len() > 0 && L >= att_mfma_min_len()) {
+  // The matrix-core kernel is a block-serial walk over the keys (two passes, a barrier pair per 64 keys): it wins where
+  // its grid fills the chip or the row is long (the other kernel's cost per query grows with L twice: scores and p.v on
+  // the vector ALUs); a short row in a small batch (batch-1 latency at 258 frames: 10 blocks) stays with the other one.
+  const long long blocks64 = (long long)((L + 63) / 64) * H * B;
+  if (att_mfma_min_len() > 0 && L >= att_mfma_min_len() && (L >= 2 * att_mfma_min_len() || blocks64 >= device_cu_count())) {
     // 128 queries a block when that still gives every CU two blocks, else 64
     if ((long long)((L + 127) / 128) * H * B >= 2LL * device_cu_count())
       attention_mfma_launch<4>(qkv, emb_k, emb_v, lengths, out, B, H, L, s);

@@ -962,7 +962,11 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
       for (int j = 0; j < n_side; ++j) HIP_TRY(hipStreamWaitEvent(m->side[j], m->ev_fork, 0));
     }
     for (int j = 0; j < nk; ++j) {
-      hipStream_t sj = (j == 0 || n_side == 0) ? s : m->side[std::min(j, n_side) - 1];
+      // One side stream: the last chain (the widest kernel, about as much work as the others together) keeps the
+      // caller's stream and the others share the side stream; more: a stream per chain.
+      hipStream_t sj = n_side == 0 ? s
+                       : n_side + 1 >= nk ? (j == 0 ? s : m->side[j - 1])
+                       : (j == nk - 1 ? s : m->side[std::min(j, n_side - 1)]);
       const ResBlock& rb = m->rbs[i * nk + j];
       const float* yin = X;
       // One decision per chain: the fused pair ping-pongs between Y and T (its blocks read a halo of their input, so
