@@ -6,7 +6,7 @@
 # Every GPU step has its own time limit and the script stops at the first failure.
 set -e
 R="$PWD"; O="$R/gpurun_out/refresh"; mkdir -p "$O"
-P="--steps 5 --warmup 2 --no-cpu-baseline --no-latency --serial-generator --no-overlap"
+P="--steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-sub-results --serial-generator --no-overlap"
 WHAT="${*:-profile workloads}"
 if [[ "$WHAT" == *profile* ]]; then
   cd /tmp && export TMPDIR=/tmp

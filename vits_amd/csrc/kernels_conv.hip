@@ -1274,6 +1274,15 @@ __device__ __forceinline__ void gl_static_for(F& f) {
   }
 }
 
+// one step's operand fragments: weights (m-tile 0/1, planes h/l) and activations (n-tile 0..3, planes h/l)
+struct GlFrags {
+  gl_u32x4 ah0, al0, ah1, al1, bh0, bh1, bl0, bl1, bh2, bh3, bl2, bl3;
+};
+__device__ __forceinline__ void gl_zero_frags(GlFrags& f) {
+  const gl_u32x4 z = {0u, 0u, 0u, 0u};
+  f.ah0 = f.al0 = f.ah1 = f.al1 = f.bh0 = f.bh1 = f.bl0 = f.bl1 = f.bh2 = f.bh3 = f.bl2 = f.bl3 = z;
+}
+
 template <int WN, int WGM, int WGN, int K, int D, int A>
 __global__ __launch_bounds__(256, 2) void conv_gl_kernel(const ConvArgs a) {
   constexpr int WM = 2;
@@ -1373,74 +1382,105 @@ __global__ __launch_bounds__(256, 2) void conv_gl_kernel(const ConvArgs a) {
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_void*)gl_lds;
   const unsigned a_addr = lds_base + (unsigned)(((wm * WM * 2) * 64 + lane) * 16);
   const unsigned b_addr = lds_base + (unsigned)((S * WU + par * 2 * NCOLS + wn * 32 * WN + l31) * 16);
-  int s = 0;
-  for (int c = 0; c < nchunks; ++c) {
-    const unsigned xb = b_addr + (unsigned)(buf_rd * 4 * NCOLS * 16);
-    auto tap = [&](auto kk) __attribute__((always_inline)) {
-      constexpr int k = decltype(kk)::value;
-      constexpr int allowed = (D - 1) * WPK + APC * gl_tap0_in_window(k, K, D);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allowed) : "memory");
-      __builtin_amdgcn_s_barrier();
-      const unsigned wa = a_addr + (unsigned)(slot_rd * WU * 16);
-      const unsigned xk = xb + (unsigned)(k * dil * 16);
-      gl_u32x4 ah0, al0, ah1, al1, bh0, bh1, bh2, bh3, bl0, bl1, bl2, bl3;
+  // The fragments of step u are read while the MFMAs of step u - 1 run: two register sets, alternating.  A step is
+  //   wait (this wave's DMA share of step u has landed; the reads of step u - 1 have) -> s_barrier (every wave's)
+  //   -> reads of step u -> DMA requests of step u + D, into the slot step u - 1 has just left -> MFMAs of step u - 1.
+  GlFrags f0, f1;
+  gl_zero_frags(f1);
+  auto read_frags = [&](GlFrags& f, unsigned wa, unsigned xk) __attribute__((always_inline)) {
+    asm volatile(
+        "ds_read_b128 %0, %4\n\t"
+        "ds_read_b128 %1, %4 offset:1024\n\t"
+        "ds_read_b128 %2, %4 offset:2048\n\t"
+        "ds_read_b128 %3, %4 offset:3072"
+        : "=&v"(f.ah0), "=&v"(f.al0), "=&v"(f.ah1), "=&v"(f.al1)
+        : "v"(wa)
+        : "memory");
+    asm volatile(
+        "ds_read_b128 %0, %4\n\t"
+        "ds_read_b128 %1, %4 offset:512\n\t"
+        "ds_read_b128 %2, %4 offset:%c5\n\t"
+        "ds_read_b128 %3, %4 offset:%c6"
+        : "=&v"(f.bh0), "=&v"(f.bh1), "=&v"(f.bl0), "=&v"(f.bl1)
+        : "v"(xk), "i"(NCOLS * 16), "i"(NCOLS * 16 + 512)
+        : "memory");
+    if constexpr (WN == 4)
       asm volatile(
-          "ds_read_b128 %0, %4\n\t"
-          "ds_read_b128 %1, %4 offset:1024\n\t"
-          "ds_read_b128 %2, %4 offset:2048\n\t"
-          "ds_read_b128 %3, %4 offset:3072"
-          : "=&v"(ah0), "=&v"(al0), "=&v"(ah1), "=&v"(al1)
-          : "v"(wa)
-          : "memory");
-      asm volatile(
-          "ds_read_b128 %0, %4\n\t"
-          "ds_read_b128 %1, %4 offset:512\n\t"
+          "ds_read_b128 %0, %4 offset:1024\n\t"
+          "ds_read_b128 %1, %4 offset:1536\n\t"
           "ds_read_b128 %2, %4 offset:%c5\n\t"
           "ds_read_b128 %3, %4 offset:%c6"
-          : "=&v"(bh0), "=&v"(bh1), "=&v"(bl0), "=&v"(bl1)
-          : "v"(xk), "i"(NCOLS * 16), "i"(NCOLS * 16 + 512)
+          : "=&v"(f.bh2), "=&v"(f.bh3), "=&v"(f.bl2), "=&v"(f.bl3)
+          : "v"(xk), "i"(NCOLS * 16 + 1024), "i"(NCOLS * 16 + 1536)
           : "memory");
+  };
+  // the three products of a step, from a register set whose reads have been waited for
+  auto mma3 = [&](const GlFrags& f) __attribute__((always_inline)) {
+    const gl_u32x4 Ah[WM] = {f.ah0, f.ah1}, Al[WM] = {f.al0, f.al1};
+    gl_u32x4 Bh[WN], Bl[WN];
+    Bh[0] = f.bh0; Bh[1] = f.bh1; Bl[0] = f.bl0; Bl[1] = f.bl1;
+    if constexpr (WN == 4) { Bh[2] = f.bh2; Bh[3] = f.bh3; Bl[2] = f.bl2; Bl[3] = f.bl3; }
+    mma(Ah, Bl);                                       // h * l
+    mma(Ah, Bh);                                       // h * h
+    mma(Al, Bh);                                       // l * h
+  };
+  int s = 0;
+  for (int c0 = 0; c0 < nchunks; c0 += 2) {        // two chunks a trip: the register sets swap at compile time
+    auto step = [&](auto jj) __attribute__((always_inline)) {
+      constexpr int j = decltype(jj)::value;
+      constexpr int k = j % K;
+      constexpr int allowed = (D - 1) * WPK + APC * gl_tap0_in_window(k, K, D);
+      GlFrags& cur = (j & 1) ? f1 : f0;
+      GlFrags& prev = (j & 1) ? f0 : f1;
+      // the wait names every register of the previous set, so nothing touches them before their reads have landed
       if constexpr (WN == 4)
-        asm volatile(
-            "ds_read_b128 %0, %4 offset:1024\n\t"
-            "ds_read_b128 %1, %4 offset:1536\n\t"
-            "ds_read_b128 %2, %4 offset:%c5\n\t"
-            "ds_read_b128 %3, %4 offset:%c6"
-            : "=&v"(bh2), "=&v"(bh3), "=&v"(bl2), "=&v"(bl3)
-            : "v"(xk), "i"(NCOLS * 16 + 1024), "i"(NCOLS * 16 + 1536)
-            : "memory");
-      // the DMA requests of the steps ahead go out while the fragment reads are in flight
-      if constexpr (k == 0) issue_x(c + A, buf_wr);
-      issue_w(s + D, slot_wr);
-      // the wait names every fragment register, so nothing touches them before the reads have landed, and the
-      // scheduling barrier keeps the MFMAs (register-only, not ordered by a memory clobber) below it
-      if constexpr (WN == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ah0), "+v"(al0), "+v"(ah1), "+v"(al1), "+v"(bh0), "+v"(bh1), "+v"(bl0), "+v"(bl1), "+v"(bh2),
-                       "+v"(bh3), "+v"(bl2), "+v"(bl3)
-                     :
+        asm volatile("s_waitcnt vmcnt(%12) lgkmcnt(0)"
+                     : "+v"(prev.ah0), "+v"(prev.al0), "+v"(prev.ah1), "+v"(prev.al1), "+v"(prev.bh0), "+v"(prev.bh1),
+                       "+v"(prev.bl0), "+v"(prev.bl1), "+v"(prev.bh2), "+v"(prev.bh3), "+v"(prev.bl2), "+v"(prev.bl3)
+                     : "n"(allowed)
                      : "memory");
       else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ah0), "+v"(al0), "+v"(ah1), "+v"(al1), "+v"(bh0), "+v"(bh1), "+v"(bl0), "+v"(bl1)
-                     :
+        asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)"
+                     : "+v"(prev.ah0), "+v"(prev.al0), "+v"(prev.ah1), "+v"(prev.al1), "+v"(prev.bh0), "+v"(prev.bh1),
+                       "+v"(prev.bl0), "+v"(prev.bl1)
+                     : "n"(allowed)
                      : "memory");
+      __builtin_amdgcn_s_barrier();
+      read_frags(cur, a_addr + (unsigned)(slot_rd * WU * 16),
+                 b_addr + (unsigned)(buf_rd * 4 * NCOLS * 16) + (unsigned)(k * dil * 16));
+      // the scheduling barriers keep the MFMAs (register-only, not ordered by a memory clobber) between the reads of
+      // this step and its DMA requests; those go last because a vector-memory request can hold the wave at issue until
+      // the load path has room, and here that wait runs into the one for the next step's data
       __builtin_amdgcn_sched_barrier(0);
-      const gl_u32x4 Ah[WM] = {ah0, ah1}, Al[WM] = {al0, al1};
-      gl_u32x4 Bh[WN], Bl[WN];
-      Bh[0] = bh0; Bh[1] = bh1; Bl[0] = bl0; Bl[1] = bl1;
-      if constexpr (WN == 4) { Bh[2] = bh2; Bh[3] = bh3; Bl[2] = bl2; Bl[3] = bl3; }
-      mma(Ah, Bl);                                       // h * l
-      mma(Ah, Bh);                                       // h * h
-      mma(Al, Bh);                                       // l * h
+      if (j > 0 || c0 > 0) mma3(prev);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (k == 0) issue_x(c0 + j / K + A, buf_wr);
+      issue_w(s + D, slot_wr);
       ++s;
       slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
       slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
+      if constexpr (k == K - 1) {
+        buf_rd = buf_rd + 1 == NBUF ? 0 : buf_rd + 1;
+        buf_wr = buf_wr + 1 == NBUF ? 0 : buf_wr + 1;
+      }
     };
-    gl_static_for<0, K>(tap);
-    buf_rd = buf_rd + 1 == NBUF ? 0 : buf_rd + 1;
-    buf_wr = buf_wr + 1 == NBUF ? 0 : buf_wr + 1;
+    gl_static_for<0, 2 * K>(step);
   }
+  // the last step's products (an even number of steps: its fragments are in the second set)
+  if constexpr (WN == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f1.ah0), "+v"(f1.al0), "+v"(f1.ah1), "+v"(f1.al1), "+v"(f1.bh0), "+v"(f1.bh1), "+v"(f1.bl0),
+                   "+v"(f1.bl1), "+v"(f1.bh2), "+v"(f1.bh3), "+v"(f1.bl2), "+v"(f1.bl3)
+                 :
+                 : "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f1.ah0), "+v"(f1.al0), "+v"(f1.ah1), "+v"(f1.al1), "+v"(f1.bh0), "+v"(f1.bh1), "+v"(f1.bl0),
+                   "+v"(f1.bl1)
+                 :
+                 : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  mma3(f1);
   // nothing of this block may still be on its way into LDS when the block's LDS is handed to the next one
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -1599,7 +1639,7 @@ static bool gl_wide() {
 // rows allow, else 64 x 256.  Returns false when the launch is not one of them.
 static bool try_launch_gl(ConvArgs& a, hipStream_t stream, hipError_t& err) {
   if (!gl_enabled() || !(a.flags & F_IN_STAGED) || a.in_cbias || a.cbias || (a.flags & (F_IN_MASK | F_IN_LRELU))) return false;
-  if (a.M % 64 || (a.K != 3 && a.K != 7 && a.K != 11) || a.tstep[0] < 1) return false;
+  if (a.M % 64 || a.Cin % 32 || (a.K != 3 && a.K != 7 && a.K != 11) || a.tstep[0] < 1) return false;   // chunks go in pairs
   if ((long long)a.Cin * a.K * a.M * 4 >= (1LL << 31) || (long long)a.L * 16 >= (1LL << 31)) return false;
   const bool tall = a.M % 128 == 0;
   auto blocks_of = [&](int bn) { return (long long)((a.L + bn - 1) / bn) * (a.M / (tall ? 128 : 64)) * a.B; };
