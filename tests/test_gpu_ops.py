@@ -227,6 +227,55 @@ def test_conv_staged_pair(N, pname, C, k, dil, L, B):
         assert torch.equal(lo, (act - h).to(torch.float16).float())
 
 
+@pytest.mark.parametrize("C,k,dil,L,kind", [(128, 11, 5, 16512, "res"), (128, 3, 1, 16400, "staged_out"),
+                                            (256, 7, 3, 2064, "res"), (256, 11, 1, 2000, "plain"),
+                                            (64, 3, 5, 9000, "res"), (64, 7, 9, 8190, "staged_out"),
+                                            (64, 11, 5, 8193, "res_acc")])
+def test_conv_lds_dma_matches_register_kernel(N, C, k, dil, L, kind):
+    """Staged-input f16x2 convs whose grid fills the chip run on the kernel that brings weights and activations into
+    LDS by DMA (128 x 256, 128 x 128 and 64 x 256 block tiles); a single batch row is a small grid and stays with the
+    register-staging kernel.  Same operands in the same order: a batch of 16 must give the bytes its rows give one at
+    a time -- at both sequence ends (the DMA's out-of-range lanes are the zero padding), across tile borders, for every
+    epilogue the generator uses (residual, residual + accumulate, staged output, plain)."""
+    from vits_amd import weights
+    p = PREC["f16x2"]
+    g = torch.Generator().manual_seed(C * 31 + k * 7 + L)
+    B = 16
+    w0 = torch.randn(C, C, 3, generator=g) / math.sqrt(C * 3)
+    w = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    pk0, pk = dev(weights.pack_rows(w0, p)), dev(weights.pack_rows(w, p))
+    b0, b = dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g))
+    x = dev(torch.randn(B, C, L, generator=g))
+    init = dev(torch.randn(B, C, L, generator=g))
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = N.F_IN_STAGED | {"res": N.F_RES, "res_acc": N.F_RES | N.F_ACCUM, "staged_out": N.F_OUT_STAGED, "plain": 0}[kind]
+
+    def run(xr, out):
+        n = xr.shape[0]
+        staged = torch.empty(n, C, L, device="cuda")
+        N.check(N.lib.vits_op_conv1d(pk0.data_ptr(), b0.data_ptr(), C, C, 3, 1, 0, p, xr.data_ptr(), n, L, 0, 0, 0, 0,
+                                     staged.data_ptr(), N.F_IN_LRELU | N.F_OUT_STAGED, 1.0, 0.1, stream), "first conv")
+        N.check(N.lib.vits_op_conv1d(pk.data_ptr(), b.data_ptr(), C, C, k, dil, 0, p, staged.data_ptr(), n, L, 0, 0, 0,
+                                     xr.data_ptr() if flags & N.F_RES else 0, out.data_ptr(), flags, 1.0, 0.1, stream),
+                "second conv")
+        return out
+
+    whole = run(x, init.clone())
+    for i in (0, 9, 15):
+        row = run(x[i:i + 1].contiguous(), init[i:i + 1].clone())
+        torch.cuda.synchronize()
+        assert torch.equal(row[0].view(torch.int32), whole[i].view(torch.int32))      # bytes (staged output is fp16 pairs)
+    if kind != "staged_out":
+        xc = x[:2].cpu()
+        t = F.leaky_relu(F.conv1d(F.leaky_relu(xc, 0.1), w0, b0.cpu(), padding=1), 0.1)
+        ref = F.conv1d(t, w, b.cpu(), padding=(k - 1) // 2 * dil, dilation=dil)
+        if flags & N.F_RES:
+            ref = ref + xc
+        if flags & N.F_ACCUM:
+            ref = ref + init[:2].cpu()
+        assert (whole[:2].cpu() - ref).abs().max() < 5e-5
+
+
 @pytest.mark.parametrize("C,k,dil,L,B,acc", [(32, 3, 1, 1000, 2, False), (32, 7, 3, 3000, 2, True),
                                              (32, 11, 5, 2500, 3, False), (32, 11, 1, 224, 1, True),
                                              (32, 3, 5, 225, 2, False), (32, 7, 5, 50, 2, False),
@@ -338,16 +387,18 @@ def reference_attention(q, k, v, ek, ev, lengths, H, W=4):
     return out.transpose(2, 3).reshape(B, C, L)
 
 
-@pytest.mark.parametrize("L", [3, 12, 50, 130, 255, 256, 258, 600, 861, 1400])
-def test_attention(N, L):
-    """L < 256: the lanes-on-keys kernel; L >= 256: the matrix-core kernel (bf16x3 products, two passes over the keys).
+@pytest.mark.parametrize("L,B", [(3, 2), (12, 2), (50, 2), (130, 2), (255, 2), (256, 2), (258, 2), (600, 2), (861, 2),
+                                 (1400, 2), (256, 70), (258, 64), (300, 33), (511, 17)])
+def test_attention(N, L, B):
+    """Short rows and small grids: the lanes-on-keys kernel; L >= 512, and L >= 256 when the batch fills the chip with
+    64-query blocks: the matrix-core kernel (bf16x3 products, two passes over the keys; 64- and 128-query blocks).
     Both against the reference's own formulation (padded relative embeddings, skew reshapes)."""
     g = torch.Generator().manual_seed(L)
-    B, H, dk = 2, 2, 96
+    H, dk = 2, 96
     C = H * dk
     qkv = torch.randn(B, 3 * C, L, generator=g)
     ek, ev = torch.randn(9, dk, generator=g) * 0.1, torch.randn(9, dk, generator=g) * 0.1
-    lengths = torch.tensor([L, max(1, (2 * L) // 3)], dtype=torch.int32)
+    lengths = torch.tensor([L, max(1, (2 * L) // 3)] + [max(1, L - 7 * i) for i in range(B - 2)], dtype=torch.int32)
     ref = reference_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ek, ev, lengths, H)
     out = torch.empty(B, C, L, device="cuda")
     qd, kd, vd, ld = dev(qkv), dev(ek), dev(ev), dev(lengths)

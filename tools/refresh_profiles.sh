@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box from the repo root: regenerates the raw material for profiles/ under gpurun_out/refresh.
 #   tools/refresh_profiles.sh [profile] [workloads]     (default: both)
-# profile:   kernel trace + the two counter passes over the same short bench command
+# profile:   kernel trace + the two counter passes over the same short bench command, and a kernel trace of six batch-1 calls
 # workloads: bench lines of the other shapes and of the plain-bf16 generator mode
 # Every GPU step has its own time limit and the script stops at the first failure.
 set -e
@@ -13,6 +13,8 @@ if [[ "$WHAT" == *profile* ]]; then
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o kt -- python3 "$R/bench.py" $P > "$O/kt_bench.json" 2> "$O/kt.log"
   cd "$R"
   bash tools/pmc_traffic.sh "$O/pmc" python3 "$R/bench.py" $P
+  cd /tmp
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/b1" -o b1 -- python3 "$R/tools/b1_trace.py" > "$O/b1.log" 2>&1
   cd "$R"
 fi
 if [[ "$WHAT" == *workloads* ]]; then
