@@ -1,7 +1,5 @@
 #!/bin/bash
 set -o pipefail
-for sh in "64 861" "16 258" "64 1400" "1 258" "16 600"; do
-  for m in 256 100000; do
-    VITS_ATT_MFMA=$m timeout -k 10 100 python tools/bench_attention.py $sh 2>&1 | tail -1 || exit 1
-  done
-done
+R=$PWD; O=$R/gpurun_out/b1n; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o b1 -- python3 "$R/tools/b1_trace.py" > "$O/b1.log" 2>&1 || exit 1

@@ -1770,7 +1770,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
       for (int ci = 0; ci < 16; ++ci) st[q][ci] = (xc + (long long)ci * a.x_cs)[toff];    // raw: store_chunk zeroes
     }
   };
-  auto store_chunk = [&]() __attribute__((always_inline)) {
+  auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
+    const float* cbp = a.in_cbias ? a.in_cbias + (long long)b * a.in_cbias_bs + chunk * 16 : nullptr;
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
       const int col = lane + 64 * q, t = tstart + col;
@@ -1783,7 +1784,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
         float v[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          float x = st[q][2 * c2 + u] * a.in_scale;
+          float x = st[q][2 * c2 + u];
+          if (cbp) x += cbp[2 * c2 + u];
+          x *= a.in_scale;
           if (a.flags & F_IN_LRELU) x = fmaxf(x, x * a.in_slope);
           v[u] = ok ? x : 0.f;
         }
@@ -1842,7 +1845,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
     lda(Am[0], w0, 1);
     lda(Al, w0, 2);
     load_chunk(chunk);
-    store_chunk();
+    store_chunk(chunk);
     if (chunk + NW < nchunks) load_chunk(chunk + NW);
     ldb(Bh[0], 0, boff);
     ldb(Bm[0], 1, boff);
@@ -1885,7 +1888,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
         chunk += NW;
         boff = colbase + a.toff0[0];
         if (more) {
-          store_chunk();
+          store_chunk(chunk);
           if (chunk + NW < nchunks) load_chunk(chunk + NW);
           ldb(Bh[n], 0, boff);
           ldb(Bm[n], 1, boff);
@@ -1990,7 +1993,8 @@ static bool ks8_enabled() {
 
 template <int MODE>
 static bool try_launch_ks(ConvArgs& a, hipStream_t stream, hipError_t& err) {
-  if (!ks_enabled() || a.M % 64 != 0 || a.Cin < 64 || a.in_cbias) return false;
+  // rows: whole 64-row units, or (plain convs) a last unit with one 32-row tile -- the 96-row projections of the flow
+  if (!ks_enabled() || a.Cin < 64 || (MODE == MODE_GATE ? a.M % 64 != 0 : a.M % 32 != 0)) return false;
   const int n32 = (a.L + 31) / 32;
   const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + 1) / 2;
   const int cus = device_cu_count();
