@@ -365,6 +365,26 @@ def test_generator_chain_with_unfusable_pair(synthetic_sd):
     assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= MEL_TOL
 
 
+def test_infer_long_utterance_beyond_2048_frames(gpu_model, oracle_model):
+    """An utterance of 2600 frames (30 s): past the 2048 positions the lanes-on-keys attention kernel can hold, the
+    frame-rate encoder runs on the matrix-core attention kernel, which walks the keys in tiles and has no such bound.
+    One row against the oracle, every returned tensor; and the limit that remains (16384 frames) is an error, not a
+    wrong answer."""
+    b = synthetic.make_batch(71, [130], [2600])
+    kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
+    got = gpu_model.infer(b.phonemes, b.lengths, **kw)
+    ref = oracle_model.infer(b.phonemes, b.lengths, **kw)
+    assert got[0].shape == ref[0].shape == (1, 1, 2600 * 512)
+    assert metrics.max_abs(got[0], ref[0]) <= WAV_TOL
+    assert metrics.log_mel_l1(got[0][:, 0], ref[0][:, 0]) <= MEL_TOL
+    for name, x, y in zip(("z", "z_p", "m_p", "logs_p"), got[2], ref[2]):
+        assert metrics.max_abs(x, y) <= LATENT_TOL, name
+    too_long = synthetic.make_batch(72, [200], [16500])
+    with pytest.raises((ValueError, RuntimeError)):
+        gpu_model.infer(too_long.phonemes, too_long.lengths, sid=too_long.sid, noise_scale=too_long.noise_scale,
+                        duration_control=too_long.durations, noise=too_long.noise)
+
+
 def test_f16x2_range_overflow_is_reported(synthetic_sd):
     """The default arithmetic (f16x2) clamps activations to the fp16 range.  A checkpoint whose generator leaves that
     range must be reported: range_overflow() turns true, the next infer warns once and names precision="bf16x3"

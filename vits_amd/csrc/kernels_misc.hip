@@ -581,7 +581,7 @@ static int att_mfma_min_len() {
 
 hipError_t launch_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
                             int B, int H, int DK, int L, int window, hipStream_t s) {
-  if (DK != ATT_DK || window != ATT_W || B <= 0 || L <= 0 || L > 2048 || B > 65535) return hipErrorInvalidValue;
+  if (DK != ATT_DK || window != ATT_W || B <= 0 || L <= 0 || L > 16384 || B > 65535) return hipErrorInvalidValue;
   // The matrix-core kernel is a block-serial walk over the keys (two passes, a barrier pair per 64 keys): it wins where
   // its grid fills the chip or the row is long (the other kernel's cost per query grows with L twice: scores and p.v on
   // the vector ALUs); a short row in a small batch (batch-1 latency at 258 frames: 10 blocks) stays with the other one.
@@ -594,6 +594,7 @@ hipError_t launch_attention(const float* qkv, const float* emb_k, const float* e
       attention_mfma_launch<2>(qkv, emb_k, emb_v, lengths, out, B, H, L, s);
     return hipGetLastError();
   }
+  if (L > 2048) return hipErrorInvalidValue;       // the lanes-on-keys kernel holds a whole score row in registers
   const int nch = (L + 63) / 64;
 #define ATT_LAUNCH(N, Q) attention_launch<N, Q>(qkv, emb_k, emb_v, lengths, out, B, H, L, s)
   // The score row lives in registers: QPW * NCH floats per lane, so longer rows take fewer queries per wave.

@@ -700,7 +700,7 @@ int vits_frame_prior(const vits_model* m, float* x_frame, const int* frame_lengt
                      float noise_scale, float* stats, float* z_p, float* z, void* ws, int64_t ws_bytes, void* stream) {
   CHECK_MODEL(m);
   hipStream_t s = (hipStream_t)stream;
-  if (T > 2048) return fail(VITS_ERR_INVALID, "attention kernel supports at most 2048 frames per utterance");
+  if (T > 16384) return fail(VITS_ERR_INVALID, "at most 16384 frames per utterance");
   Arena ar(ws, ws_bytes);
   TRY(run_encoder(m, 2, x_frame, frame_lengths, B, T, ar, s));
   TRY(conv_simple(m->project, x_frame, stats, B, T, frame_lengths, F_MASK_PRE, s));

@@ -399,8 +399,8 @@ class SynthesizerTrn:
         if y.dim() != 3 or y.shape[1] != self.cfg.spec_channels:
             raise ValueError(f"y must be [B, {self.cfg.spec_channels}, T]")
         B, S, T = y.shape
-        if T > 2048:
-            raise ValueError("at most 2048 frames per utterance")
+        if T > 16384:
+            raise ValueError("at most 16384 frames per utterance")
         IC = self.cfg.inter_channels
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev), self._exclusive():
