@@ -56,6 +56,11 @@ int vits_model_alive(const vits_model* m);
  * one per ResBlock kernel size.  A caller that drives further streams of its own lowers it to stay within the
  * process's hardware queues (4 by default).  No counterpart in the reference. */
 int vits_model_set_generator_streams(vits_model* m, int n_streams);
+/* The encoders' post-LN sub-layers (reference attentions.py:32-44, modules.py:15-27): with on != 0 (the default, unless
+ * VITS_LN_FUSED=0) a LayerNorm is not a kernel of its own -- the conv that produces x + f(x) writes per-time-step
+ * statistics and the convs that consume the normalised tensor apply it while they load; with 0 every LayerNorm is a
+ * separate launch.  Same values to rounding (the statistics are merged from 64-channel partial sums). */
+int vits_model_set_ln_fused(vits_model* m, int on);
 /* Register a device int32 (zeroed by the caller) that the f16x2 kernels OR 1 into whenever they clamp an activation
  * to the fp16 range (+-65504) during vits_generator; NULL switches reporting off.  No counterpart in the reference
  * (its fp32 convs have no such range). */

@@ -241,8 +241,9 @@ def test_infer_batches_equals_infer(gpu_model):
 
 
 def test_infer_at_the_length_limits(gpu_model, oracle_model):
-    """Longest supported utterance: 2048 frames (the attention kernel keeps a whole score row in registers) from
-    400 phonemes, against the oracle; one frame more is refused with a clear error rather than computed wrongly."""
+    """A 2048-frame utterance (the longest row the lanes-on-keys attention kernel could hold; rows of 512 and more now
+    run on the matrix-core kernel) from 400 phonemes, against the oracle; a row beyond the remaining limit of 16384
+    frames is refused with a clear error rather than computed wrongly."""
     b = synthetic.make_batch(41, [400], [2048])
     kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
     o = gpu_model.infer(b.phonemes, b.lengths, **kw)[0]
@@ -250,8 +251,8 @@ def test_infer_at_the_length_limits(gpu_model, oracle_model):
     ref = oracle_model.infer(b.phonemes, b.lengths, **kw)[0]
     assert metrics.max_abs(o, ref) <= WAV_TOL
     assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= MEL_TOL
-    longer = synthetic.make_batch(42, [400], [2049])
-    with pytest.raises(Exception, match="2048"):
+    longer = synthetic.make_batch(42, [400], [16385])
+    with pytest.raises(Exception, match="16384"):
         gpu_model.infer(longer.phonemes, longer.lengths, sid=longer.sid, noise_scale=0.667,
                         duration_control=longer.durations, noise=longer.noise)
     # the model still works after the refused call
@@ -368,8 +369,7 @@ def test_generator_chain_with_unfusable_pair(synthetic_sd):
 def test_infer_long_utterance_beyond_2048_frames(gpu_model, oracle_model):
     """An utterance of 2600 frames (30 s): past the 2048 positions the lanes-on-keys attention kernel can hold, the
     frame-rate encoder runs on the matrix-core attention kernel, which walks the keys in tiles and has no such bound.
-    One row against the oracle, every returned tensor; and the limit that remains (16384 frames) is an error, not a
-    wrong answer."""
+    One row against the oracle, every returned tensor."""
     b = synthetic.make_batch(71, [130], [2600])
     kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
     got = gpu_model.infer(b.phonemes, b.lengths, **kw)
@@ -379,10 +379,33 @@ def test_infer_long_utterance_beyond_2048_frames(gpu_model, oracle_model):
     assert metrics.log_mel_l1(got[0][:, 0], ref[0][:, 0]) <= MEL_TOL
     for name, x, y in zip(("z", "z_p", "m_p", "logs_p"), got[2], ref[2]):
         assert metrics.max_abs(x, y) <= LATENT_TOL, name
-    too_long = synthetic.make_batch(72, [200], [16500])
-    with pytest.raises((ValueError, RuntimeError)):
-        gpu_model.infer(too_long.phonemes, too_long.lengths, sid=too_long.sid, noise_scale=too_long.noise_scale,
-                        duration_control=too_long.durations, noise=too_long.noise)
+
+
+def test_layer_norm_in_the_convs_matches_separate_kernels(synthetic_sd, oracle_model):
+    """The encoders' LayerNorms are not kernels by default: the conv that produces x + f(x) writes per-time-step
+    statistics and the consumers normalise while they load.  Against the same model with every LayerNorm as its own
+    launch (vits_model_set_ln_fused(0)): the same tensors to rounding, on a ragged batch (statistics of padded steps,
+    masks) at a phoneme-rate and a frame-rate grid that take the split-K kernel and at a frame-rate grid large enough
+    for the one-role kernel; and each against the oracle."""
+    from vits_amd import _native as N
+    net = _model(synthetic_sd)
+    for seed, pc, fc in ((81, [23, 9, 17], [130, 41, 99]), (82, [60] * 40, [700] * 39 + [333])):
+        b = synthetic.make_batch(seed, pc, fc)
+        kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
+        N.check(N.lib.vits_model_set_ln_fused(net._handle, 1), "set_ln_fused")
+        fused = net.infer(b.phonemes, b.lengths, **kw)
+        N.check(N.lib.vits_model_set_ln_fused(net._handle, 0), "set_ln_fused")
+        plain = net.infer(b.phonemes, b.lengths, **kw)
+        N.check(N.lib.vits_model_set_ln_fused(net._handle, 1), "set_ln_fused")
+        for name, x, y in zip(("z", "z_p", "m_p", "logs_p"), fused[2], plain[2]):
+            assert metrics.max_abs(x, y) <= 2e-5, name
+        assert metrics.max_abs(fused[4], plain[4]) <= 1e-2                      # F0 in Hz
+        assert metrics.max_abs(fused[0], plain[0]) <= 2e-5
+        if len(pc) <= 4:
+            ref = oracle_model.infer(b.phonemes, b.lengths, **kw)
+            assert metrics.max_abs(fused[0], ref[0]) <= WAV_TOL
+            for name, x, y in zip(("z", "z_p", "m_p", "logs_p"), fused[2], ref[2]):
+                assert metrics.max_abs(x, y) <= LATENT_TOL, name
 
 
 def test_f16x2_range_overflow_is_reported(synthetic_sd):

@@ -85,7 +85,29 @@ struct ConvArgs {
                                                      // f16x2 format (leaky-relu(out_slope) applied), for the next conv
   int* range_flag;                                   // PREC_F16X2: OR 1 into *range_flag when an activation lies outside
                                                      // the fp16 range and was clamped (null: not reported)
+  // Deferred LayerNorm over channels (PREC_BF16X3, MODE_PLAIN).  A producer leaves its result un-normalised and writes,
+  // per time step and 64-row unit, (sum, sum of squared deviations from the unit's mean) to ln_out_stats
+  // [B][L][M / 64][2]; a consumer normalises on the fly -- its input at staging (ln_in_*: statistics of the Cin input
+  // channels) and / or its residual in the epilogue (ln_res_*: of the M rows) -- as (v - mean) * rstd * gamma[c] + beta[c]
+  // with eps 1e-5 and the biased variance (reference modules.py:15-27).
+  const float* ln_in_stats; const float* ln_in_gamma; const float* ln_in_beta;
+  const float* ln_res_stats; const float* ln_res_gamma; const float* ln_res_beta;
+  float* ln_out_stats;
 };
+
+// mean and 1 / sqrt(var + eps) of one time step from the per-unit partial statistics (Chan's combination of
+// (sum, M2) pairs over units of 64 channels)
+__device__ __forceinline__ void ln_combine(const float* __restrict__ st, int units, float& mean, float& rstd) {
+  float total = 0.f;
+  for (int u = 0; u < units; ++u) total += st[2 * u];
+  mean = total / (64.f * (float)units);
+  float m2 = 0.f;
+  for (int u = 0; u < units; ++u) {
+    const float d = st[2 * u] * (1.f / 64.f) - mean;
+    m2 += st[2 * u + 1] + 64.f * d * d;
+  }
+  rstd = 1.f / sqrtf(m2 / (64.f * (float)units) + 1e-5f);
+}
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
 

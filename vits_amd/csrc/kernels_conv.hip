@@ -142,10 +142,12 @@ __device__ __forceinline__ void staged_f16x2_store(const ConvArgs& a, const floa
 // All loads of a tile are issued before its first store: out may alias res (in-place residual update), so a
 // per-element load -> store sequence would serialise 16 memory round trips.
 // ---------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int MODE, bool RES_ALL = false>
+// LN: the deferred-LayerNorm options of ConvArgs (ln_res_*, ln_out_stats) are honoured (the bf16x3 kernels).
+// ln_pre: the residual's (mean, 1 / std) per n-tile when the caller has already combined them (else null).
+template <int WM, int WN, int MODE, bool RES_ALL = false, bool LN = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[WM][WN], const int (&mt)[WM],
                                               const bool (&mt_ok)[WM], int wn, int par, int l31, int t0, int b,
-                                              int len_b) {
+                                              int len_b, const float (*ln_pre)[2] = nullptr) {
   const float* cbias_b = a.cbias ? a.cbias + (long long)b * a.cbias_bs : nullptr;
   float* out_b = a.out + (long long)b * a.out_bs;
   if constexpr (MODE == MODE_PLAIN) {
@@ -161,6 +163,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
     // registers); otherwise one 32-row block at a time.
     constexpr int RI = RES_ALL ? WM : 1;
     float rv[RI][WN][16];
+    // deferred LayerNorm of the residual: this lane's time steps' mean and 1 / std, once
+    float rmean[WN], rrstd[WN];
+    bool ln_res = false;
+    if constexpr (LN) {
+      ln_res = a.ln_res_stats && res_b;
+      if (ln_res) {
+        const int units = a.M >> 6;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int t = t0 + (wn * WN + j) * 32 + l31;
+          if (ln_pre) {
+            rmean[j] = ln_pre[j][0];
+            rrstd[j] = ln_pre[j][1];
+          } else {
+            ln_combine(a.ln_res_stats + ((long long)b * a.L + (t < a.L ? t : a.L - 1)) * units * 2, units, rmean[j], rrstd[j]);
+          }
+        }
+      }
+    }
     auto load_res = [&](int i, int slot) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
@@ -169,8 +190,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           rv[slot][j][r] = (res_b + (long long)(mt[i] * 32 + (r & 3) + 8 * (r >> 2)) * a.res_cs)[lo_res];
+        if constexpr (LN) {
+          if (ln_res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = mt[i] * 32 + 4 * par + (r & 3) + 8 * (r >> 2);
+              rv[slot][j][r] = (rv[slot][j][r] - rmean[j]) * rrstd[j] * a.ln_res_gamma[row] + a.ln_res_beta[row];
+            }
+          }
+        }
       }
     };
+    // statistics of the result for a deferred LayerNorm: (sum, M2) of the lane's 16 values per m-tile, merged below
+    float psum[WM][WN], pm2[WM][WN];
+    if constexpr (LN) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) psum[i][j] = pm2[i][j] = 0.f;
+    }
     if constexpr (RES_ALL) {
       if (flags & (F_RES | F_RES_SUB)) {
 #pragma unroll
@@ -227,6 +265,40 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
             (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = v;
           }
           if (a.out2) staged_f16x2_store(a, fv, reinterpret_cast<uint2*>(a.out2 + (long long)b * a.out2_bs), mt[i], par, t);
+          if constexpr (LN) {
+            if (a.ln_out_stats) {
+              float s16 = 0.f, q16 = 0.f;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) s16 += fv[r];
+              const float mu = s16 * (1.f / 16.f);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) q16 += (fv[r] - mu) * (fv[r] - mu);
+              psum[i][j] = s16;
+              pm2[i][j] = q16;
+            }
+          }
+        }
+      }
+    }
+    if constexpr (LN && WM == 2) {
+      if (a.ln_out_stats && mt_ok[0] && mt_ok[1]) {
+        // Chan's merge of (sum, M2) pairs: the lane's two m-tiles (16 + 16 values), then lane ^ 32 (32 + 32): the 64
+        // rows of the unit at this time step
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int t = t0 + (wn * WN + j) * 32 + l31;
+          const float d1 = (psum[0][j] - psum[1][j]) * (1.f / 16.f);
+          float sum = psum[0][j] + psum[1][j];
+          float m2 = pm2[0][j] + pm2[1][j] + d1 * d1 * 8.f;              // n_a n_b / (n_a + n_b) = 16 * 16 / 32
+          const float osum = __shfl_xor(sum, 32), om2 = __shfl_xor(m2, 32);
+          const float d2 = (sum - osum) * (1.f / 32.f);
+          m2 = m2 + om2 + d2 * d2 * 16.f;                                // 32 * 32 / 64
+          sum += osum;
+          if (par == 0 && t < a.L) {
+            float* so = a.ln_out_stats + (((long long)b * a.L + t) * (a.M >> 6) + (mt[0] >> 1)) * 2;
+            so[0] = sum;
+            so[1] = m2;
+          }
         }
       }
     }
@@ -523,7 +595,9 @@ __device__ __forceinline__ unsigned pack_bf16(__bf16 lo, __bf16 hi) {
   return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
 }
 
-template <int WM, int WN, int WGM, int WGN, int MODE>
+// LN: the deferred-LayerNorm options of ConvArgs are honoured (an instantiation of its own: the extra registers would
+// cost the plain one its third block per CU).
+template <int WM, int WN, int WGM, int WGN, int MODE, bool LN = false>
 __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
   constexpr int BN = 32 * WN * WGN;
   constexpr int NCT = (BN + MAX_HALO + 255) / 256;       // tile columns per thread
@@ -550,7 +624,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
   const float* xb = a.x + (long long)b * a.x_bs;
   const int tstart = t0 + a.min_off;
   const int wcols = a.width;
-  float st[NCT][16];
+  float st[NCT][16], lng[LN ? 16 : 1], lnb[LN ? 16 : 1];
   auto load_chunk = [&](int chunk) {
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
@@ -562,6 +636,30 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
       for (int ci = 0; ci < 16; ++ci) {
         const float v = xc[(long long)ci * a.x_cs];
         st[q][ci] = ok ? v : 0.f;
+      }
+    }
+    if constexpr (LN) {
+      if (a.ln_in_stats) {                             // the chunk's LayerNorm gains and biases travel with it
+#pragma unroll
+        for (int ci = 0; ci < 16; ++ci) {
+          lng[ci] = a.ln_in_gamma[chunk * 16 + ci];
+          lnb[ci] = a.ln_in_beta[chunk * 16 + ci];
+        }
+      }
+    }
+  };
+  // deferred LayerNorm of the input: mean and 1 / std of this thread's tile columns, once -- requested behind the
+  // first chunk's loads, so that the two round trips overlap
+  float lnm[LN ? NCT : 1], lnr[LN ? NCT : 1];
+  auto ln_columns = [&]() {
+    if constexpr (LN) {
+      if (!a.ln_in_stats) return;
+      const int units = a.Cin >> 6;
+#pragma unroll
+      for (int q = 0; q < NCT; ++q) {
+        const int t = tstart + tid + 256 * q;
+        const int tc = t < 0 ? 0 : t < a.L ? t : a.L - 1;
+        ln_combine(a.ln_in_stats + ((long long)b * a.L + tc) * units * 2, units, lnm[q], lnr[q]);
       }
     }
   };
@@ -580,7 +678,11 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int ci = 2 * c2 + u;
-            float v = (st[q][ci] + (cbp ? cbp[ci] : 0.f)) * a.in_scale;
+            float xin = st[q][ci];
+            if constexpr (LN) {
+              if (a.ln_in_stats) xin = (xin - lnm[q]) * lnr[q] * lng[ci] + lnb[ci];
+            }
+            float v = (xin + (cbp ? cbp[ci] : 0.f)) * a.in_scale;
             if (a.flags & F_IN_LRELU) v = fmaxf(v, v * a.in_slope);
             v = ok ? v : 0.f;
             h[u] = (__bf16)v;                       // x = h + m + l exactly to 24 significant bits
@@ -627,6 +729,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
   int it = 0;
 
   load_chunk(0);
+  ln_columns();
   store_chunk(0);
   __syncthreads();
 
@@ -692,7 +795,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
     }
   }
 
-  conv_epilogue<WM, WN, MODE, true>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+  conv_epilogue<WM, WN, MODE, true, LN>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1555,6 +1658,15 @@ static hipError_t launch_b3(ConvArgs& a, hipStream_t stream) {
   dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
   const size_t lds = (size_t)6 * a.rs * sizeof(uint4);
   char name[96];
+  if constexpr (MODE == MODE_PLAIN && WM == 2) {
+    if (a.ln_in_stats || a.ln_res_stats || a.ln_out_stats) {         // the deferred-LayerNorm instantiation
+      snprintf(name, sizeof name, "conv_bf16x3_kernel<%d,%d,%d,%d,%d,ln>", WM, WN, WGM, WGN, MODE);
+      return timed_launch(name, false, a, stream, [&] {
+        hipLaunchKernelGGL((conv_bf16x3_kernel<WM, WN, WGM, WGN, MODE, true>), grid, dim3(256), lds, stream, a);
+      });
+    }
+  }
+  if (a.ln_in_stats || a.ln_res_stats || a.ln_out_stats) return hipErrorInvalidValue;
   snprintf(name, sizeof name, "conv_bf16x3_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
   return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_bf16x3_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
@@ -1758,7 +1870,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
   const float* xb = a.x + (long long)b * a.x_bs;
   const int tstart = t0 + a.min_off;
   const int wcols = a.width;
-  float st[NCT][16];
+  float st[NCT][16], lng[16], lnb[16];
   auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
@@ -1768,6 +1880,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
       const float* xc = xb + (long long)chunk * 16 * a.x_cs;
 #pragma unroll
       for (int ci = 0; ci < 16; ++ci) st[q][ci] = (xc + (long long)ci * a.x_cs)[toff];    // raw: store_chunk zeroes
+    }
+    if (a.ln_in_stats) {                               // the chunk's LayerNorm gains and biases travel with it
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci) {
+        lng[ci] = a.ln_in_gamma[chunk * 16 + ci];
+        lnb[ci] = a.ln_in_beta[chunk * 16 + ci];
+      }
+    }
+  };
+  // deferred LayerNorm of the input: mean and 1 / std of this lane's tile columns, once -- requested behind the first
+  // chunk's loads, so that the two round trips overlap
+  float lnm[NCT], lnr[NCT];
+  auto ln_columns = [&]() __attribute__((always_inline)) {
+    if (!a.ln_in_stats) return;
+    const int units = a.Cin >> 6;
+#pragma unroll
+    for (int q = 0; q < NCT; ++q) {
+      const int t = tstart + lane + 64 * q;
+      const int tc = t < 0 ? 0 : t < a.L ? t : a.L - 1;
+      ln_combine(a.ln_in_stats + ((long long)b * a.L + tc) * units * 2, units, lnm[q], lnr[q]);
     }
   };
   auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
@@ -1785,6 +1917,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           float x = st[q][2 * c2 + u];
+          if (a.ln_in_stats) x = (x - lnm[q]) * lnr[q] * lng[2 * c2 + u] + lnb[2 * c2 + u];
           if (cbp) x += cbp[2 * c2 + u];
           x *= a.in_scale;
           if (a.flags & F_IN_LRELU) x = fmaxf(x, x * a.in_slope);
@@ -1845,6 +1978,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
     lda(Am[0], w0, 1);
     lda(Al, w0, 2);
     load_chunk(chunk);
+    ln_columns();
     store_chunk(chunk);
     if (chunk + NW < nchunks) load_chunk(chunk + NW);
     ldb(Bh[0], 0, boff);
@@ -1905,6 +2039,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
     if (s < S) step(IntC<0>{});
   }
 
+  // the residual's LayerNorm statistics (wave 0 runs the epilogue): requested before the reduction's barriers
+  float ln_pre[WN][2];
+  const bool ln_res = a.ln_res_stats && a.res && wave == 0;
+  if (ln_res) {
+    const int units = a.M >> 6;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int t = t0 + j * 32 + l31;
+      ln_combine(a.ln_res_stats + ((long long)b * a.L + (t < a.L ? t : a.L - 1)) * units * 2, units, ln_pre[j][0], ln_pre[j][1]);
+    }
+  }
   // ---- fixed-order reduction of the four partial sums through LDS: (w0 + w2) + (w1 + w3) ----
   __syncthreads();                                              // every wave is done with its staging region
   float* red = reinterpret_cast<float*>(xq);                    // [NW / 2 slots][WM * WN * 16][64 lanes]
@@ -1939,7 +2084,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
   __syncthreads();
   if (wave == 0) {
     add(0);
-    conv_epilogue<WM, WN, MODE>(a, acc, mt, mt_ok, 0, par, l31, t0, b, len_b);
+    conv_epilogue<WM, WN, MODE, false, true>(a, acc, mt, mt_ok, 0, par, l31, t0, b, len_b, ln_res ? ln_pre : nullptr);
   }
 }
 
@@ -2068,6 +2213,12 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
                       (a.flags & (F_OUT_STAGED | F_IN_STAGED)) || ((a.flags | a.flags_hi) & F_RES_SUB)))
     return hipErrorInvalidValue;
   if (a.out2 && (d.mode != MODE_PLAIN || p != PREC_F16X2 || (a.flags & F_OUT_STAGED))) return hipErrorInvalidValue;
+  // deferred LayerNorm: the bf16x3 kernels' 64-row wave tiles only; statistics are per 64-channel unit
+  if (a.ln_in_stats || a.ln_res_stats || a.ln_out_stats) {
+    if (d.mode != MODE_PLAIN || p != PREC_BF16X3 || M % 64 || a.split_row) return hipErrorInvalidValue;
+    if (a.ln_in_stats && (d.Cin % 64 || !a.ln_in_gamma || !a.ln_in_beta)) return hipErrorInvalidValue;
+    if (a.ln_res_stats && (!a.res || !a.ln_res_gamma || !a.ln_res_beta)) return hipErrorInvalidValue;
+  }
   if (p == PREC_BF16X3 && (d.mode == MODE_PLAIN || d.mode == MODE_GATE)) {
     hipError_t err = hipSuccess;
     ConvArgs ak = a;

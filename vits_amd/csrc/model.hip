@@ -76,6 +76,15 @@ struct ResBlock {
 
 }  // namespace
 
+// VITS_LN_FUSED=0: every LayerNorm of the encoders is a kernel of its own (the default of vits_model_set_ln_fused).
+static bool ln_fused_default() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_LN_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 struct vits_model {
   vits_config cfg{};
   std::map<std::string, Plain> plain;
@@ -105,6 +114,7 @@ struct vits_model {
   hipEvent_t ev_fork = nullptr, ev_done[8] = {};
   int n_side = 0;
   int side_limit = 8;                // vits_model_set_generator_streams: how many of them vits_generator may use
+  bool ln_fused = ln_fused_default();   // vits_model_set_ln_fused: the encoders' LayerNorms ride in the neighbouring convs
   int* range_flag = nullptr;         // vits_model_set_range_flag
 };
 
@@ -188,10 +198,10 @@ ConvArgs base_args(const float* x, long long x_bs, int x_cs, float* out, long lo
 // floats per batch row of a staged activation tensor with C channels (bf16: 2 bytes per element, f16x2: 4)
 inline long long staged_row_floats(int prec, int C, int L) { return prec == PREC_BF16 ? (long long)C * L / 2 : (long long)C * L; }
 
-int conv_simple(const ConvDesc& d, const float* x, float* out, int B, int L, const int* lengths, int flags,
-                hipStream_t s, const float* res = nullptr, const float* cbias = nullptr, int cbias_bs = 0,
-                const float* in_cbias = nullptr, int in_cbias_bs = 0, float in_scale = 1.f, float in_slope = 1.f,
-                float out_slope = 1.f, float* out2 = nullptr) {
+ConvArgs conv_simple_args(const ConvDesc& d, const float* x, float* out, int B, int L, const int* lengths, int flags,
+                          const float* res = nullptr, const float* cbias = nullptr, int cbias_bs = 0,
+                          const float* in_cbias = nullptr, int in_cbias_bs = 0, float in_scale = 1.f, float in_slope = 1.f,
+                          float out_slope = 1.f, float* out2 = nullptr) {
   ConvArgs a = base_args(x, (long long)d.Cin * L, L, out, (long long)d.cout * L * d.up, L * d.up, B, L, lengths, flags);
   a.out2 = out2; a.out2_bs = (long long)d.cout * L;          // staged f16x2 copy: as many bytes per element as fp32
   if (flags & F_IN_STAGED) a.x_bs = staged_row_floats(d.prec, d.Cin, L);
@@ -202,7 +212,15 @@ int conv_simple(const ConvDesc& d, const float* x, float* out, int B, int L, con
   a.in_cbias = in_cbias; a.in_cbias_bs = in_cbias_bs;
   a.in_scale = in_scale; a.in_slope = in_slope;
   a.range_flag = g_range_flag;
-  HIP_TRY(launch_conv(d, a, s));
+  return a;
+}
+
+int conv_simple(const ConvDesc& d, const float* x, float* out, int B, int L, const int* lengths, int flags,
+                hipStream_t s, const float* res = nullptr, const float* cbias = nullptr, int cbias_bs = 0,
+                const float* in_cbias = nullptr, int in_cbias_bs = 0, float in_scale = 1.f, float in_slope = 1.f,
+                float out_slope = 1.f, float* out2 = nullptr) {
+  HIP_TRY(launch_conv(d, conv_simple_args(d, x, out, B, L, lengths, flags, res, cbias, cbias_bs, in_cbias, in_cbias_bs,
+                                          in_scale, in_slope, out_slope, out2), s));
   return VITS_OK;
 }
 
@@ -214,7 +232,9 @@ int conv_simple(const ConvDesc& d, const float* x, float* out, int B, int L, con
 
 int64_t encoder_ws_floats(const vits_model* m, int B, int L) {
   const int64_t C = m->cfg.hidden_channels, F = m->cfg.filter_channels;
-  return (pad256((int64_t)B * 3 * C * L) + pad256((int64_t)B * C * L) + pad256((int64_t)B * F * L)) / 4;
+  // q|k|v, attention output, FFN hidden, and two tables of LayerNorm statistics (per time step and 64-channel unit)
+  return (pad256((int64_t)B * 3 * C * L) + pad256((int64_t)B * C * L) + pad256((int64_t)B * F * L) +
+          2 * pad256((int64_t)B * L * ((C + 63) / 64) * 2)) / 4;
 }
 
 int run_encoder(const vits_model* m, int which, float* x, const int* lengths, int B, int L, Arena& ar, hipStream_t s) {
@@ -224,15 +244,59 @@ int run_encoder(const vits_model* m, int which, float* x, const int* lengths, in
   float* h = ar.take((int64_t)B * F * L);
   if (!qkv || !att || !h) return fail(VITS_ERR_WORKSPACE, "encoder: workspace too small");
   const auto& layers = m->enc[which];
+  // Post-LN sub-layers, x = norm(x + f(x)) (reference attentions.py:32-44).  Deferred form: the conv that produces
+  // x + f(x) leaves it un-normalised and writes per-time-step statistics; the convs that read it (q|k|v, the FFN's first
+  // conv) normalise at staging and the next residual add normalises in its epilogue, so only the encoder's last
+  // LayerNorm is a kernel.  Needs the bf16x3 kernels and whole 64-channel units.
+  bool deferred = m->ln_fused && C % 64 == 0 && !layers.empty();
+  for (const EncLayer& l : layers)
+    deferred = deferred && l.qkv.prec == PREC_BF16X3 && l.o.prec == PREC_BF16X3 && l.ffn1.prec == PREC_BF16X3 &&
+               l.ffn2.prec == PREC_BF16X3;
+  float* st[2] = {nullptr, nullptr};
+  if (deferred) {
+    st[0] = ar.take((int64_t)B * L * (C / 64) * 2);
+    st[1] = ar.take((int64_t)B * L * (C / 64) * 2);
+    if (!st[0] || !st[1]) return fail(VITS_ERR_WORKSPACE, "encoder: workspace too small");
+  }
+  const float *pg = nullptr, *pb = nullptr, *ps = nullptr;      // the pending LayerNorm of x: gain, bias, statistics
   for (size_t i = 0; i < layers.size(); ++i) {
     const EncLayer& l = layers[i];
-    TRY(conv_simple(l.qkv, x, qkv, B, L, lengths, 0, s));
+    if (!deferred) {
+      TRY(conv_simple(l.qkv, x, qkv, B, L, lengths, 0, s));
+      HIP_TRY(launch_attention(qkv, l.ek, l.ev, lengths, att, B, H, C / H, L, m->cfg.window_size, s));
+      TRY(conv_simple(l.o, att, x, B, L, lengths, F_RES, s, x));
+      HIP_TRY(launch_layer_norm(x, x, l.ln1g, l.ln1b, lengths, B, C, L, false, s));
+      TRY(conv_simple(l.ffn1, x, h, B, L, lengths, F_IN_MASK | F_RELU, s));
+      TRY(conv_simple(l.ffn2, h, x, B, L, lengths, F_IN_MASK | F_MASK_PRE | F_RES, s, x));
+      HIP_TRY(launch_layer_norm(x, x, l.ln2g, l.ln2b, lengths, B, C, L, i + 1 == layers.size(), s));
+      continue;
+    }
+    const bool last = i + 1 == layers.size();
+    {
+      ConvArgs a = conv_simple_args(l.qkv, x, qkv, B, L, lengths, 0);
+      a.ln_in_stats = ps; a.ln_in_gamma = pg; a.ln_in_beta = pb;
+      HIP_TRY(launch_conv(l.qkv, a, s));
+    }
     HIP_TRY(launch_attention(qkv, l.ek, l.ev, lengths, att, B, H, C / H, L, m->cfg.window_size, s));
-    TRY(conv_simple(l.o, att, x, B, L, lengths, F_RES, s, x));
-    HIP_TRY(launch_layer_norm(x, x, l.ln1g, l.ln1b, lengths, B, C, L, false, s));
-    TRY(conv_simple(l.ffn1, x, h, B, L, lengths, F_IN_MASK | F_RELU, s));
-    TRY(conv_simple(l.ffn2, h, x, B, L, lengths, F_IN_MASK | F_MASK_PRE | F_RES, s, x));
-    HIP_TRY(launch_layer_norm(x, x, l.ln2g, l.ln2b, lengths, B, C, L, i + 1 == layers.size(), s));
+    {
+      ConvArgs a = conv_simple_args(l.o, att, x, B, L, lengths, F_RES, x);
+      a.ln_res_stats = ps; a.ln_res_gamma = pg; a.ln_res_beta = pb;
+      a.ln_out_stats = st[0];
+      HIP_TRY(launch_conv(l.o, a, s));
+    }
+    {
+      ConvArgs a = conv_simple_args(l.ffn1, x, h, B, L, lengths, F_IN_MASK | F_RELU);
+      a.ln_in_stats = st[0]; a.ln_in_gamma = l.ln1g; a.ln_in_beta = l.ln1b;
+      HIP_TRY(launch_conv(l.ffn1, a, s));
+    }
+    {
+      ConvArgs a = conv_simple_args(l.ffn2, h, x, B, L, lengths, F_IN_MASK | F_MASK_PRE | F_RES, x);
+      a.ln_res_stats = st[0]; a.ln_res_gamma = l.ln1g; a.ln_res_beta = l.ln1b;
+      a.ln_out_stats = last ? nullptr : st[1];
+      HIP_TRY(launch_conv(l.ffn2, a, s));
+    }
+    if (last) HIP_TRY(launch_layer_norm(x, x, l.ln2g, l.ln2b, lengths, B, C, L, true, s));
+    pg = l.ln2g; pb = l.ln2b; ps = st[1];
   }
   return VITS_OK;
 }
@@ -336,6 +400,12 @@ int vits_model_set_generator_streams(vits_model* m, int n_streams) {
   if (!model_alive(m)) return fail(VITS_ERR_INVALID, "set_generator_streams: not a live model handle");
   if (n_streams < 1) return fail(VITS_ERR_INVALID, "set_generator_streams: at least the caller's stream");
   m->side_limit = n_streams - 1;
+  return VITS_OK;
+}
+
+int vits_model_set_ln_fused(vits_model* m, int on) {
+  if (!model_alive(m)) return fail(VITS_ERR_INVALID, "set_ln_fused: not a live model handle");
+  m->ln_fused = on != 0;
   return VITS_OK;
 }
 
