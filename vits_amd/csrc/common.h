@@ -85,7 +85,7 @@ struct ConvArgs {
                                                      // f16x2 format (leaky-relu(out_slope) applied), for the next conv
   int* range_flag;                                   // PREC_F16X2: OR 1 into *range_flag when an activation lies outside
                                                      // the fp16 range and was clamped (null: not reported)
-  // Deferred LayerNorm over channels (PREC_BF16X3, MODE_PLAIN).  A producer leaves its result un-normalised and writes,
+  // Deferred LayerNorm over channels (PREC_BF16X3, MODE_PLAIN, split-K kernel: conv_takes_split_k).  A producer leaves its result un-normalised and writes,
   // per time step and 64-row unit, (sum, sum of squared deviations from the unit's mean) to ln_out_stats
   // [B][L][M / 64][2]; a consumer normalises on the fly -- its input at staging (ln_in_*: statistics of the Cin input
   // channels) and / or its residual in the epilogue (ln_res_*: of the M rows) -- as (v - mean) * rstd * gamma[c] + beta[c]
@@ -110,6 +110,9 @@ __device__ __forceinline__ void ln_combine(const float* __restrict__ st, int uni
 }
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
+// true when launch_conv would run this conv on the split-K kernel for a batch of B rows of L steps (the only kernel
+// that honours ConvArgs::ln_*)
+bool conv_takes_split_k(const ConvDesc& d, int B, int L);
 
 // One ResBlock pair in one launch (32-channel stage, PREC_F16X2): out = x + c2(lrelu(c1(lrelu(x)))) [+ out], with the
 // tensor between the two convs kept in LDS.  x and out must not overlap (blocks read a halo of x).

@@ -144,7 +144,13 @@ __device__ __forceinline__ void staged_f16x2_store(const ConvArgs& a, const floa
 // ---------------------------------------------------------------------------------------------------------
 // LN: the deferred-LayerNorm options of ConvArgs (ln_res_*, ln_out_stats) are honoured (the bf16x3 kernels).
 // ln_pre: the residual's (mean, 1 / std) per n-tile when the caller has already combined them (else null).
-template <int WM, int WN, int MODE, bool RES_ALL = false, bool LN = false>
+// EXTRA: the optional features a kernel's epilogue is built with -- each costs registers, and the kernels that run three
+// blocks to a CU have none to spare (with all of them built in, every such kernel spilled 48-60 bytes):
+//   EPI_LN     the deferred-LayerNorm options of ConvArgs (ln_res_*, ln_out_stats): the split-K kernel
+//   EPI_SPLIT  a second destination for the rows from split_row on: the kernels that run the flow (fp32, bf16x3)
+//   EPI_OUT2   a second, staged copy of the result: the staged-input f16x2 kernels
+constexpr int EPI_LN = 1, EPI_SPLIT = 2, EPI_OUT2 = 4;
+template <int WM, int WN, int MODE, bool RES_ALL = false, int EXTRA = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[WM][WN], const int (&mt)[WM],
                                               const bool (&mt_ok)[WM], int wn, int par, int l31, int t0, int b,
                                               int len_b, const float (*ln_pre)[2] = nullptr) {
@@ -152,11 +158,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
   float* out_b = a.out + (long long)b * a.out_bs;
   if constexpr (MODE == MODE_PLAIN) {
     const float* res_b = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+    constexpr bool LN = (EXTRA & EPI_LN) != 0;
     int flags = a.flags;
-    if (a.split_row > 0 && mt[0] * 32 >= a.split_row) {      // the wave's rows belong to the second destination
-      out_b = a.out_hi + (long long)b * a.out_hi_bs - (long long)a.split_row * a.out_cs;
-      flags = a.flags_hi;
-      res_b = nullptr;
+    if constexpr ((EXTRA & EPI_SPLIT) != 0) {
+      if (a.split_row > 0 && mt[0] * 32 >= a.split_row) {    // the wave's rows belong to the second destination
+        out_b = a.out_hi + (long long)b * a.out_hi_bs - (long long)a.split_row * a.out_cs;
+        flags = a.flags_hi;
+        res_b = nullptr;
+      }
     }
     // Residual loads go out before the first store of the rows they cover (out may alias res element for element,
     // which this order keeps correct).  RES_ALL: the whole wave tile at once (one memory round trip, WM * WN * 16
@@ -251,7 +260,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
             for (int r = 0; r < 16; ++r)
               ov[r] = (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out];
           }
-          float fv[16];
+          float fv[(EXTRA & (EPI_OUT2 | EPI_LN)) ? 16 : 1];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[i][j][r] + bz[r];
@@ -261,10 +270,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
             if (flags & F_RES_SUB) v = rv[ri][j][r] - v;
             if (flags & F_ACCUM) v += ov[r];
             if (flags & F_MASK_POST) v *= m;
-            fv[r] = v;
+            if constexpr ((EXTRA & (EPI_OUT2 | EPI_LN)) != 0) fv[r] = v;
             (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = v;
           }
-          if (a.out2) staged_f16x2_store(a, fv, reinterpret_cast<uint2*>(a.out2 + (long long)b * a.out2_bs), mt[i], par, t);
+          if constexpr ((EXTRA & EPI_OUT2) != 0) {
+            if (a.out2)
+              staged_f16x2_store(a, fv, reinterpret_cast<uint2*>(a.out2 + (long long)b * a.out2_bs), mt[i], par, t);
+          }
           if constexpr (LN) {
             if (a.ln_out_stats) {
               float s16 = 0.f, q16 = 0.f;
@@ -280,7 +292,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
         }
       }
     }
-    if constexpr (LN && WM == 2) {
+    if constexpr ((EXTRA & EPI_LN) != 0 && WM == 2) {
       if (a.ln_out_stats && mt_ok[0] && mt_ok[1]) {
         // Chan's merge of (sum, M2) pairs: the lane's two m-tiles (16 + 16 values), then lane ^ 32 (32 + 32): the 64
         // rows of the unit at this time step
@@ -419,7 +431,8 @@ __device__ __forceinline__ void wave_mtiles(const ConvArgs& a, int wm, int (&mt)
 // dwordx4 loads and ds_write_b128 (a group of four time steps is then entirely inside or outside [0, L)).
 // LDS tile: [16 channels][rs] fp32; MFMA B fragments are conflict-free ds_read_b32 (lanes = consecutive t).
 // ---------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int WGM, int WGN, int MODE, bool VEC>
+// EX: optional epilogue features (EPI_*), each an instantiation of its own
+template <int WM, int WN, int WGM, int WGN, int MODE, bool VEC, int EX = 0>
 __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int BN = 32 * WN * WGN;
   constexpr int NCOLS = VEC ? (BN + MAX_HALO + 4 + 255) / 256 : (BN + MAX_HALO + 63) / 64;
@@ -579,7 +592,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
 
-  conv_epilogue<WM, WN, MODE, true>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+  conv_epilogue<WM, WN, MODE, true, EX>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -595,9 +608,8 @@ __device__ __forceinline__ unsigned pack_bf16(__bf16 lo, __bf16 hi) {
   return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
 }
 
-// LN: the deferred-LayerNorm options of ConvArgs are honoured (an instantiation of its own: the extra registers would
-// cost the plain one its third block per CU).
-template <int WM, int WN, int WGM, int WGN, int MODE, bool LN = false>
+// EX: optional epilogue features (EPI_*), each an instantiation of its own
+template <int WM, int WN, int WGM, int WGN, int MODE, int EX = 0>
 __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
   constexpr int BN = 32 * WN * WGN;
   constexpr int NCT = (BN + MAX_HALO + 255) / 256;       // tile columns per thread
@@ -624,7 +636,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
   const float* xb = a.x + (long long)b * a.x_bs;
   const int tstart = t0 + a.min_off;
   const int wcols = a.width;
-  float st[NCT][16], lng[LN ? 16 : 1], lnb[LN ? 16 : 1];
+  float st[NCT][16];
   auto load_chunk = [&](int chunk) {
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
@@ -636,30 +648,6 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
       for (int ci = 0; ci < 16; ++ci) {
         const float v = xc[(long long)ci * a.x_cs];
         st[q][ci] = ok ? v : 0.f;
-      }
-    }
-    if constexpr (LN) {
-      if (a.ln_in_stats) {                             // the chunk's LayerNorm gains and biases travel with it
-#pragma unroll
-        for (int ci = 0; ci < 16; ++ci) {
-          lng[ci] = a.ln_in_gamma[chunk * 16 + ci];
-          lnb[ci] = a.ln_in_beta[chunk * 16 + ci];
-        }
-      }
-    }
-  };
-  // deferred LayerNorm of the input: mean and 1 / std of this thread's tile columns, once -- requested behind the
-  // first chunk's loads, so that the two round trips overlap
-  float lnm[LN ? NCT : 1], lnr[LN ? NCT : 1];
-  auto ln_columns = [&]() {
-    if constexpr (LN) {
-      if (!a.ln_in_stats) return;
-      const int units = a.Cin >> 6;
-#pragma unroll
-      for (int q = 0; q < NCT; ++q) {
-        const int t = tstart + tid + 256 * q;
-        const int tc = t < 0 ? 0 : t < a.L ? t : a.L - 1;
-        ln_combine(a.ln_in_stats + ((long long)b * a.L + tc) * units * 2, units, lnm[q], lnr[q]);
       }
     }
   };
@@ -678,11 +666,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int ci = 2 * c2 + u;
-            float xin = st[q][ci];
-            if constexpr (LN) {
-              if (a.ln_in_stats) xin = (xin - lnm[q]) * lnr[q] * lng[ci] + lnb[ci];
-            }
-            float v = (xin + (cbp ? cbp[ci] : 0.f)) * a.in_scale;
+            float v = (st[q][ci] + (cbp ? cbp[ci] : 0.f)) * a.in_scale;
             if (a.flags & F_IN_LRELU) v = fmaxf(v, v * a.in_slope);
             v = ok ? v : 0.f;
             h[u] = (__bf16)v;                       // x = h + m + l exactly to 24 significant bits
@@ -729,7 +713,6 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
   int it = 0;
 
   load_chunk(0);
-  ln_columns();
   store_chunk(0);
   __syncthreads();
 
@@ -795,7 +778,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
     }
   }
 
-  conv_epilogue<WM, WN, MODE, true, LN>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+  conv_epilogue<WM, WN, MODE, true, EX>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1332,7 +1315,7 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
       return;
     }
   }
-  conv_epilogue<WM, WN, MODE, true>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+  conv_epilogue<WM, WN, MODE, true, STG ? EPI_OUT2 : 0>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1593,7 +1576,7 @@ __global__ __launch_bounds__(256, 2) void conv_gl_kernel(const ConvArgs a) {
   }
   // residual loads one 32-row block ahead of its stores for the 64 x 128 wave tile (the whole tile's would not fit in
   // registers beside the accumulators)
-  conv_epilogue<WM, WN, MODE_PLAIN, WN == 2>(a, acc, mt, mt_ok, wn, par, l31, t0, b, a.lengths ? a.lengths[b] : 0x7fffffff);
+  conv_epilogue<WM, WN, MODE_PLAIN, WN == 2, EPI_OUT2>(a, acc, mt, mt_ok, wn, par, l31, t0, b, a.lengths ? a.lengths[b] : 0x7fffffff);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1643,6 +1626,15 @@ static hipError_t launch_f32(ConvArgs& a, hipStream_t stream) {
   dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
   const size_t lds = (size_t)CI_CHUNK * a.rs * sizeof(float);
   char name[96];
+  if constexpr (MODE == MODE_PLAIN) {
+    if (a.split_row) {                                 // the instantiation with a second destination
+      snprintf(name, sizeof name, "conv_mfma_kernel<%d,%d,%d,%d,%d,%d,split>", WM, WN, WGM, WGN, MODE, (int)VEC);
+      return timed_launch(name, false, a, stream, [&] {
+        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE, VEC, EPI_SPLIT>), grid, dim3(256), lds, stream, a);
+      });
+    }
+  }
+  if (a.split_row) return hipErrorInvalidValue;
   snprintf(name, sizeof name, "conv_mfma_kernel<%d,%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE, (int)VEC);
   return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WGM, WGN, MODE, VEC>), grid, dim3(256), lds, stream, a);
@@ -1658,15 +1650,18 @@ static hipError_t launch_b3(ConvArgs& a, hipStream_t stream) {
   dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
   const size_t lds = (size_t)6 * a.rs * sizeof(uint4);
   char name[96];
-  if constexpr (MODE == MODE_PLAIN && WM == 2) {
-    if (a.ln_in_stats || a.ln_res_stats || a.ln_out_stats) {         // the deferred-LayerNorm instantiation
-      snprintf(name, sizeof name, "conv_bf16x3_kernel<%d,%d,%d,%d,%d,ln>", WM, WN, WGM, WGN, MODE);
+  // deferred LayerNorm is the split-K kernel's: its consumers pay ~2 us there, here (every thread of a block with the
+  // statistics and 32 more registers) a frame-rate conv took 80 us instead of 45
+  if (a.ln_in_stats || a.ln_res_stats || a.ln_out_stats) return hipErrorInvalidValue;
+  if constexpr (MODE == MODE_PLAIN) {
+    if (a.split_row) {                                 // the instantiation with a second destination
+      snprintf(name, sizeof name, "conv_bf16x3_kernel<%d,%d,%d,%d,%d,split>", WM, WN, WGM, WGN, MODE);
       return timed_launch(name, false, a, stream, [&] {
-        hipLaunchKernelGGL((conv_bf16x3_kernel<WM, WN, WGM, WGN, MODE, true>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((conv_bf16x3_kernel<WM, WN, WGM, WGN, MODE, EPI_SPLIT>), grid, dim3(256), lds, stream, a);
       });
     }
   }
-  if (a.ln_in_stats || a.ln_res_stats || a.ln_out_stats) return hipErrorInvalidValue;
+  if (a.split_row) return hipErrorInvalidValue;
   snprintf(name, sizeof name, "conv_bf16x3_kernel<%d,%d,%d,%d,%d>", WM, WN, WGM, WGN, MODE);
   return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_bf16x3_kernel<WM, WN, WGM, WGN, MODE>), grid, dim3(256), lds, stream, a);
@@ -1833,7 +1828,9 @@ static hipError_t launch_h2(ConvArgs& a, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------------
 // NW = waves per block that share the reduction: 4, or 8 (WN = 1 only) for the deepest reductions on the smallest
 // grids (768 channels at phoneme rate: six blocks on the chip, so the chain length is all that counts).
-template <int WN, int MODE, int NW = 4>
+// EX: optional features (EPI_SPLIT: a second destination; EPI_LN: deferred LayerNorm of input, residual and result),
+// each an instantiation of its own so that the plain one keeps its registers
+template <int WN, int MODE, int NW = 4, int EX = 0>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b3ks_kernel(const ConvArgs a) {
   static_assert(NW == 4 || (NW == 8 && WN == 1), "eight waves: one n-tile");
   constexpr int WM = 2;
@@ -1870,7 +1867,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
   const float* xb = a.x + (long long)b * a.x_bs;
   const int tstart = t0 + a.min_off;
   const int wcols = a.width;
-  float st[NCT][16], lng[16], lnb[16];
+  constexpr bool LN = (EX & EPI_LN) != 0;
+  float st[NCT][16], lng[LN ? 16 : 1], lnb[LN ? 16 : 1];
   auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NCT; ++q) {
@@ -1881,25 +1879,29 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
 #pragma unroll
       for (int ci = 0; ci < 16; ++ci) st[q][ci] = (xc + (long long)ci * a.x_cs)[toff];    // raw: store_chunk zeroes
     }
-    if (a.ln_in_stats) {                               // the chunk's LayerNorm gains and biases travel with it
+    if constexpr (LN) {
+      if (a.ln_in_stats) {                             // the chunk's LayerNorm gains and biases travel with it
 #pragma unroll
-      for (int ci = 0; ci < 16; ++ci) {
-        lng[ci] = a.ln_in_gamma[chunk * 16 + ci];
-        lnb[ci] = a.ln_in_beta[chunk * 16 + ci];
+        for (int ci = 0; ci < 16; ++ci) {
+          lng[ci] = a.ln_in_gamma[chunk * 16 + ci];
+          lnb[ci] = a.ln_in_beta[chunk * 16 + ci];
+        }
       }
     }
   };
   // deferred LayerNorm of the input: mean and 1 / std of this lane's tile columns, once -- requested behind the first
   // chunk's loads, so that the two round trips overlap
-  float lnm[NCT], lnr[NCT];
+  float lnm[LN ? NCT : 1], lnr[LN ? NCT : 1];
   auto ln_columns = [&]() __attribute__((always_inline)) {
-    if (!a.ln_in_stats) return;
-    const int units = a.Cin >> 6;
+    if constexpr (LN) {
+      if (!a.ln_in_stats) return;
+      const int units = a.Cin >> 6;
 #pragma unroll
-    for (int q = 0; q < NCT; ++q) {
-      const int t = tstart + lane + 64 * q;
-      const int tc = t < 0 ? 0 : t < a.L ? t : a.L - 1;
-      ln_combine(a.ln_in_stats + ((long long)b * a.L + tc) * units * 2, units, lnm[q], lnr[q]);
+      for (int q = 0; q < NCT; ++q) {
+        const int t = tstart + lane + 64 * q;
+        const int tc = t < 0 ? 0 : t < a.L ? t : a.L - 1;
+        ln_combine(a.ln_in_stats + ((long long)b * a.L + tc) * units * 2, units, lnm[q], lnr[q]);
+      }
     }
   };
   auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
@@ -1917,7 +1919,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           float x = st[q][2 * c2 + u];
-          if (a.ln_in_stats) x = (x - lnm[q]) * lnr[q] * lng[2 * c2 + u] + lnb[2 * c2 + u];
+          if constexpr (LN) {
+            if (a.ln_in_stats) x = (x - lnm[q]) * lnr[q] * lng[2 * c2 + u] + lnb[2 * c2 + u];
+          }
           if (cbp) x += cbp[2 * c2 + u];
           x *= a.in_scale;
           if (a.flags & F_IN_LRELU) x = fmaxf(x, x * a.in_slope);
@@ -2041,7 +2045,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
 
   // the residual's LayerNorm statistics (wave 0 runs the epilogue): requested before the reduction's barriers
   float ln_pre[WN][2];
-  const bool ln_res = a.ln_res_stats && a.res && wave == 0;
+  const bool ln_res = LN && a.ln_res_stats && a.res && wave == 0;
   if (ln_res) {
     const int units = a.M >> 6;
 #pragma unroll
@@ -2084,7 +2088,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
   __syncthreads();
   if (wave == 0) {
     add(0);
-    conv_epilogue<WM, WN, MODE, false, true>(a, acc, mt, mt_ok, 0, par, l31, t0, b, len_b, ln_res ? ln_pre : nullptr);
+    conv_epilogue<WM, WN, MODE, false, EX>(a, acc, mt, mt_ok, 0, par, l31, t0, b, len_b, ln_res ? ln_pre : nullptr);
   }
 }
 
@@ -2118,8 +2122,21 @@ static hipError_t launch_b3ks(ConvArgs& a, hipStream_t stream) {
   const size_t lds = stage > red ? stage : red;
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   char name[96];
-  if (NW == 4) snprintf(name, sizeof name, "conv_b3ks_kernel<%d,%d>", WN, MODE);
-  else snprintf(name, sizeof name, "conv_b3ks_kernel<%d,%d,%d>", WN, MODE, NW);
+  const bool ln = a.ln_in_stats || a.ln_res_stats || a.ln_out_stats;
+  if (NW == 4) snprintf(name, sizeof name, "conv_b3ks_kernel<%d,%d%s>", WN, MODE, ln ? ",ln" : a.split_row ? ",split" : "");
+  else snprintf(name, sizeof name, "conv_b3ks_kernel<%d,%d,%d%s>", WN, MODE, NW, ln ? ",ln" : a.split_row ? ",split" : "");
+  if constexpr (MODE == MODE_PLAIN) {
+    if (ln && a.split_row) return hipErrorInvalidValue;
+    if (ln)
+      return timed_launch(name, false, a, stream, [&] {
+        hipLaunchKernelGGL((conv_b3ks_kernel<WN, MODE, NW, EPI_LN>), grid, dim3(64 * NW), lds, stream, a);
+      });
+    if (a.split_row)
+      return timed_launch(name, false, a, stream, [&] {
+        hipLaunchKernelGGL((conv_b3ks_kernel<WN, MODE, NW, EPI_SPLIT>), grid, dim3(64 * NW), lds, stream, a);
+      });
+  }
+  if (ln || a.split_row) return hipErrorInvalidValue;
   return timed_launch(name, MODE == MODE_GATE, a, stream, [&] {
     hipLaunchKernelGGL((conv_b3ks_kernel<WN, MODE, NW>), grid, dim3(64 * NW), lds, stream, a);
   });
@@ -2136,28 +2153,45 @@ static bool ks8_enabled() {
   return on;
 }
 
-template <int MODE>
-static bool try_launch_ks(ConvArgs& a, hipStream_t stream, hipError_t& err) {
+// Tile width (n-tiles of 32 steps: 1..3) the split-K kernel would take this conv with, 0 when it is not a split-K
+// launch; *eight: eight waves share the reduction.  `halo` = max_off - min_off of the conv.
+static int ks_choice(bool gate, int M, int Cin, int K, int L, int B, int halo, bool* eight) {
+  *eight = false;
   // rows: whole 64-row units, or (plain convs) a last unit with one 32-row tile -- the 96-row projections of the flow
-  if (!ks_enabled() || a.Cin < 64 || (MODE == MODE_GATE ? a.M % 64 != 0 : a.M % 32 != 0)) return false;
-  const int n32 = (a.L + 31) / 32;
-  const int units = MODE == MODE_GATE ? a.mt_total / 2 : (a.mt_total + 1) / 2;
+  if (!ks_enabled() || Cin < 64 || (gate ? M % 64 != 0 : M % 32 != 0)) return 0;
+  const int n32 = (L + 31) / 32, mt_total = M / 32;
+  const int units = gate ? mt_total / 2 : (mt_total + 1) / 2;
   const int cus = device_cu_count();
   // Tile width: the launch is latency-bound, so what counts is how many block "rounds" the chip needs (blocks of
   // width 1 and 2 fit two to a CU, width 3 one) times the length of a block's chain (a fixed part + the tile width).
   int wn = 0;
   long long best = 0, best_blocks = 0;
   for (int c = 1; c <= 3; ++c) {
-    const long long blocks = (long long)((n32 + c - 1) / c) * units * a.B;
+    const long long blocks = (long long)((n32 + c - 1) / c) * units * B;
     const long long slots = (long long)cus * (c <= 2 ? 2 : 1);
     const long long cost = ((blocks + slots - 1) / slots) * (2 + c);
     if (wn == 0 || cost < best) { best = cost; wn = c; best_blocks = blocks; }
   }
   // beyond two blocks per CU the one-role kernel wins, except for deep reductions (>= 256 channels, >= 5 taps)
-  if (best_blocks > 2LL * cus && !(a.Cin >= 256 && a.K >= 5)) return false;
+  if (best_blocks > 2LL * cus && !(Cin >= 256 && K >= 5)) return 0;
   // eight waves when the chip is nearly empty and the reduction is deep: at most one block for every fourth CU, >= 32 chunks
-  if (wn == 1 && a.Cin >= 512 && best_blocks * 4 <= cus && (size_t)8 * 6 * (32 + a.width) * sizeof(uint4) <= 64 * 1024 &&
-      ks8_enabled()) {
+  *eight = wn == 1 && Cin >= 512 && best_blocks * 4 <= cus && (size_t)8 * 6 * (32 + halo) * sizeof(uint4) <= 64 * 1024 &&
+           ks8_enabled();
+  return wn;
+}
+
+bool conv_takes_split_k(const ConvDesc& d, int B, int L) {
+  bool eight;
+  return d.prec == PREC_BF16X3 && (d.mode == MODE_PLAIN || d.mode == MODE_GATE) &&
+         ks_choice(d.mode == MODE_GATE, d.M, d.Cin, d.K, L, B, d.max_off - d.min_off, &eight) > 0;
+}
+
+template <int MODE>
+static bool try_launch_ks(ConvArgs& a, hipStream_t stream, hipError_t& err) {
+  bool eight;
+  const int wn = ks_choice(MODE == MODE_GATE, a.M, a.Cin, a.K, a.L, a.B, a.width, &eight);
+  if (wn == 0) return false;
+  if (eight) {
     err = launch_b3ks<1, MODE, 8>(a, stream);
     return true;
   }
@@ -2212,7 +2246,9 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   if (a.split_row && (d.mode != MODE_PLAIN || a.split_row % 64 || a.split_row >= M || !a.out_hi || a.out2 ||
                       (a.flags & (F_OUT_STAGED | F_IN_STAGED)) || ((a.flags | a.flags_hi) & F_RES_SUB)))
     return hipErrorInvalidValue;
-  if (a.out2 && (d.mode != MODE_PLAIN || p != PREC_F16X2 || (a.flags & F_OUT_STAGED))) return hipErrorInvalidValue;
+  if (a.out2 && (d.mode != MODE_PLAIN || p != PREC_F16X2 || (a.flags & F_OUT_STAGED) || !(a.flags & F_IN_STAGED)))
+    return hipErrorInvalidValue;                       // the staged-input f16x2 kernels write it
+  if (a.split_row && p != PREC_F32 && p != PREC_BF16X3) return hipErrorInvalidValue;       // the kernels that run the flow
   // deferred LayerNorm: the bf16x3 kernels' 64-row wave tiles only; statistics are per 64-channel unit
   if (a.ln_in_stats || a.ln_res_stats || a.ln_out_stats) {
     if (d.mode != MODE_PLAIN || p != PREC_BF16X3 || M % 64 || a.split_row) return hipErrorInvalidValue;

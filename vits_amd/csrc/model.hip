@@ -247,11 +247,12 @@ int run_encoder(const vits_model* m, int which, float* x, const int* lengths, in
   // Post-LN sub-layers, x = norm(x + f(x)) (reference attentions.py:32-44).  Deferred form: the conv that produces
   // x + f(x) leaves it un-normalised and writes per-time-step statistics; the convs that read it (q|k|v, the FFN's first
   // conv) normalise at staging and the next residual add normalises in its epilogue, so only the encoder's last
-  // LayerNorm is a kernel.  Needs the bf16x3 kernels and whole 64-channel units.
+  // LayerNorm is a kernel.  Needs whole 64-channel units and every conv of the stack on the split-K kernel (short
+  // grids: phoneme rate, and frame rate at small batches), where a consumer pays ~2 us for it.
   bool deferred = m->ln_fused && C % 64 == 0 && !layers.empty();
   for (const EncLayer& l : layers)
-    deferred = deferred && l.qkv.prec == PREC_BF16X3 && l.o.prec == PREC_BF16X3 && l.ffn1.prec == PREC_BF16X3 &&
-               l.ffn2.prec == PREC_BF16X3;
+    deferred = deferred && conv_takes_split_k(l.qkv, B, L) && conv_takes_split_k(l.o, B, L) &&
+               conv_takes_split_k(l.ffn1, B, L) && conv_takes_split_k(l.ffn2, B, L);
   float* st[2] = {nullptr, nullptr};
   if (deferred) {
     st[0] = ar.take((int64_t)B * L * (C / 64) * 2);
