@@ -354,8 +354,8 @@ def spawn_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--frames", type=int, default=258, help="frames per utterance (C2: 258; C3: 861 with --batch 64)")
     ap.add_argument("--phonemes", type=int, default=50, help="phonemes per utterance (C2: 50; C3: 160)")
@@ -512,7 +512,9 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, cpu_out, cpu_batch = cpu_baseline(args.phonemes, args.frames)
+            # about 10-30 s of CPU work: the whole 16-utterance batch at 3 s an utterance, four utterances of the long ones
+            cb, cpu_out, cpu_batch = cpu_baseline(args.phonemes, args.frames,
+                                                  sample_utts=min(args.batch, 16 if args.frames <= 300 else 4))
             # the same sample through the GPU path: keeps the two numbers about the same work, and checks parity
             dd = to_device(cpu_batch, device)
             gpu_out = step(net, dd).cpu()
