@@ -1,11 +1,6 @@
 #!/bin/bash
 set -o pipefail
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 || exit 1
-( time timeout -k 10 600 python bench.py > gpurun_out/default_bench.json 2> gpurun_out/default_bench.err ) 2>&1 | tail -4 || exit 1
-python - <<'P'
-import json
-d=json.loads(open('gpurun_out/default_bench.json').read().strip().splitlines()[-1])
-print(d['metric'], d['value'], d['unit'], d['ms_per_step'], d['steps'], d['warmup'], d['dtype'])
-print(d['roofline']['kernel'], d['roofline']['frac'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
-print([ (s['workload'][:10], s['value']) for s in d['sub_results']])
-P
+mkdir -p gpurun_out/c3
+timeout -k 10 300 python3 bench.py --batch 64 --frames 861 --phonemes 160 --no-cpu-baseline --no-latency --steps 6 --warmup 2 > gpurun_out/c3/c3.json 2> gpurun_out/c3/c3.err || exit 1
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/c3 -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --batch 64 --frames 861 --phonemes 160 --no-cpu-baseline --no-latency --steps 3 --warmup 1 --serial-generator --no-overlap > $GRAFT_REPO_ROOT/gpurun_out/c3/kt.json 2> $GRAFT_REPO_ROOT/gpurun_out/c3/kt.err || exit 1
