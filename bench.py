@@ -109,7 +109,7 @@ def kernel_peak_tflops(name):
         return PEAK_FP32_MFMA_TFLOPS
     if name.startswith("conv_bf16_kernel"):
         return PEAK_BF16_MFMA_TFLOPS
-    if name.startswith(("conv_f16x2_kernel", "conv_gl_", "resblock_pair_kernel")):
+    if name.startswith(("conv_f16x2_kernel", "conv_gl_", "conv_gl16_", "resblock_pair_kernel")):
         return PEAK_F16X2_TFLOPS
     return PEAK_BF16X3_TFLOPS
 

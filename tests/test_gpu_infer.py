@@ -177,10 +177,16 @@ def test_infer_bf16_generator_mode(synthetic_sd):
         assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= BF16_MEL_TOL
 
 
+STREAM_TOL = 1e-5        # windows against the whole utterance: same operands, kernel builds that differ in summation order
+
+
 @pytest.mark.parametrize("chunk", [64, 50, 7])
 def test_infer_stream_concatenates_to_infer(gpu_model, chunk):
     """Chunked synthesis (windows of `chunk` frames + the generator's receptive field as context) must reproduce the
-    whole-utterance waveform bit for bit: every output sample sees the same operands in the same order."""
+    whole-utterance waveform: every output sample sees the same operands.  A window is a smaller grid than the whole
+    utterance, and the conv launcher picks its kernel build by grid size (the 7- / 11-tap LDS-DMA build sums products 32
+    at a time, the small-grid build 16 at a time), so the two agree to fp32 summation order -- STREAM_TOL, a tenth of the
+    parity tolerance against the reference -- and bit for bit wherever both sides run the same builds (the latents)."""
     b = synthetic.make_batch(11, [20, 14], [150, 117])            # ragged: the padded tail is part of the contract
     kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
     full = gpu_model.infer(b.phonemes, b.lengths, **kw)
@@ -192,7 +198,7 @@ def test_infer_stream_concatenates_to_infer(gpu_model, chunk):
         pieces.append(wav.clone())
         pos += wav.shape[-1]
     assert pos == st.total_samples == full[0].shape[-1]
-    assert torch.equal(torch.cat(pieces, -1), full[0])
+    assert metrics.max_abs(torch.cat(pieces, -1), full[0]) <= STREAM_TOL
     assert torch.equal(st.outputs[0], full[1]) and torch.equal(st.outputs[1][0], full[2][0])
 
 
@@ -201,7 +207,7 @@ def test_infer_stream_max_len_and_single_window(gpu_model):
     kw = dict(sid=b.sid, noise_scale=b.noise_scale, duration_control=b.durations, noise=b.noise)
     full = gpu_model.infer(b.phonemes, b.lengths, max_len=33, **kw)[0]
     got = torch.cat([w for _, w in gpu_model.infer_stream(b.phonemes, b.lengths, max_len=33, chunk_frames=16, **kw)], -1)
-    assert got.shape == full.shape == (1, 1, 33 * 512) and torch.equal(got, full)
+    assert got.shape == full.shape == (1, 1, 33 * 512) and metrics.max_abs(got, full) <= STREAM_TOL
     one = list(gpu_model.infer_stream(b.phonemes, b.lengths, chunk_frames=1000, **kw))
     assert len(one) == 1 and torch.equal(one[0][1], gpu_model.infer(b.phonemes, b.lengths, **kw)[0])
     with pytest.raises(ValueError):

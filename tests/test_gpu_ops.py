@@ -232,11 +232,14 @@ def test_conv_staged_pair(N, pname, C, k, dil, L, B):
                                             (64, 3, 5, 9000, "res"), (64, 7, 9, 8190, "staged_out"),
                                             (64, 11, 5, 8193, "res_acc")])
 def test_conv_lds_dma_matches_register_kernel(N, C, k, dil, L, kind):
-    """Staged-input f16x2 convs whose grid fills the chip run on the kernel that brings weights and activations into
+    """Staged-input f16x2 convs whose grid fills the chip run on the kernels that bring weights and activations into
     LDS by DMA (128 x 256, 128 x 128 and 64 x 256 block tiles); a single batch row is a small grid and stays with the
-    register-staging kernel.  Same operands in the same order: a batch of 16 must give the bytes its rows give one at
-    a time -- at both sequence ends (the DMA's out-of-range lanes are the zero padding), across tile borders, for every
-    epilogue the generator uses (residual, residual + accumulate, staged output, plain)."""
+    register-staging kernel.  A batch of 16 is compared with its rows one at a time -- at both sequence ends (the DMA's
+    out-of-range lanes are the zero padding), across tile borders, for every epilogue the generator uses (residual,
+    residual + accumulate, staged output, plain).  3 taps: the 32 x 32 x 16 build, same operands in the same order, the
+    same bytes.  7 and 11 taps: the 16 x 16 x 32 build sums the same products 32 at a time instead of 16, so the
+    results agree to fp32 summation order (1e-5 absolute on sums of up to 2816 products of magnitude 1..5: a few ulps)
+    rather than bit for bit."""
     from vits_amd import weights
     p = PREC["f16x2"]
     g = torch.Generator().manual_seed(C * 31 + k * 7 + L)
@@ -260,11 +263,21 @@ def test_conv_lds_dma_matches_register_kernel(N, C, k, dil, L, kind):
                 "second conv")
         return out
 
+    def values(t):
+        """fp32 values of one batch row of the result (a staged result is fp16 h / l planes [C/8][2][L][8])."""
+        if kind != "staged_out":
+            return t
+        hl = t.contiguous().view(torch.float16).reshape(C // 8, 2, L, 8).float()
+        return (hl[:, 0] + hl[:, 1]).permute(0, 2, 1).reshape(C, L)
+
     whole = run(x, init.clone())
     for i in (0, 9, 15):
         row = run(x[i:i + 1].contiguous(), init[i:i + 1].clone())
         torch.cuda.synchronize()
-        assert torch.equal(row[0].view(torch.int32), whole[i].view(torch.int32))      # bytes (staged output is fp16 pairs)
+        if k == 3:
+            assert torch.equal(row[0].view(torch.int32), whole[i].view(torch.int32))  # bytes (staged output is fp16 pairs)
+        else:
+            assert (values(row[0]) - values(whole[i])).abs().max() < 1e-5
     if kind != "staged_out":
         xc = x[:2].cpu()
         t = F.leaky_relu(F.conv1d(F.leaky_relu(xc, 0.1), w0, b0.cpu(), padding=1), 0.1)

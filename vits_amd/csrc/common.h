@@ -140,6 +140,19 @@ bool prof_enabled();
 int device_cu_count();      // compute units of the current device (256 on MI355X), cached
 void prof_reset();
 int prof_collect(std::vector<ProfRow>& rows);
+// Timing hooks for a conv launcher: prof_begin records the first event on the launch stream (when timing is on),
+// prof_end the second, and books the launch's algorithmic FLOPs and bytes under `name`.
+struct ProfTicket {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool on = false;
+};
+ProfTicket prof_begin(hipStream_t stream);
+void prof_end(const ProfTicket& t, const char* name, bool gate, const ConvArgs& a, hipStream_t stream);
+
+// LDS-DMA conv on v_mfma_f32_16x16x32_f16 (kernels_gl16.hip): the 7- / 11-tap shapes of the staged-input f16x2 convs.
+// launch_conv's LDS-DMA branch asks conv_gl16_takes after its own checks (staged input, rows % 64, grid size).
+bool conv_gl16_takes(const ConvArgs& a);
+hipError_t launch_conv_gl16(ConvArgs& a, bool wide, bool tall, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------
 // other kernels (kernels_misc.hip)

@@ -1454,9 +1454,10 @@ __global__ __launch_bounds__(256, 2) void conv_gl_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+      for (int j = 0; j < WN; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]),
                                                            __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
+      }
   };
 
   int slot_rd = 0, slot_wr = D % S;              // ring slot of the current step, and of step + D
@@ -1582,38 +1583,45 @@ __global__ __launch_bounds__(256, 2) void conv_gl_kernel(const ConvArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
+ProfTicket prof_begin(hipStream_t stream) {
+  ProfTicket t;
+  if (!g_prof_on) return t;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    t.e0 = prof_event();
+    t.e1 = prof_event();
+  }
+  t.on = true;
+  (void)hipEventRecord(t.e0, stream);
+  return t;
+}
+
+void prof_end(const ProfTicket& t, const char* name, bool gate, const ConvArgs& a, hipStream_t stream) {
+  if (!t.on) return;
+  (void)hipEventRecord(t.e1, stream);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfClass& c = g_prof[name];
+  c.flops += 2.0 * a.M * a.Cin * a.K * (double)a.L * a.B;     // algorithmic: dense over every position
+  // every input and output element once, fp32: rows * L outputs (half of that after the gate), residual and
+  // accumulated-output reads where the epilogue has them, the packed weights once
+  const double outs = (gate ? 0.5 : 1.0) * a.M;
+  const int reads = ((a.flags & (F_RES | F_RES_SUB)) ? 1 : 0) + ((a.flags & F_ACCUM) ? 1 : 0);
+  const double wbytes = strstr(name, "conv_mfma") || strstr(name, "conv_f16x2") || strstr(name, "conv_gl") ||
+                                strstr(name, "resblock_pair") ? 4.0
+                        : strstr(name, "conv_bf16_kernel") ? 2.0 : 6.0;
+  const double sb = strstr(name, "conv_bf16_kernel") ? 2.0 : 4.0;           // bytes per staged element
+  const double in_b = (a.flags & F_IN_STAGED) ? sb : 4.0, out_b = (a.flags & F_OUT_STAGED) ? sb : 4.0;
+  c.bytes += (double)a.L * a.B * (in_b * a.Cin + outs * (out_b + 4.0 * reads + (a.out2 ? 4.0 : 0.0))) + wbytes * a.M * a.Cin * a.K;
+  c.count += 1;
+  c.pending.emplace_back(t.e0, t.e1);
+}
+
 template <typename Launch>
 static hipError_t timed_launch(const char* name, bool gate, const ConvArgs& a, hipStream_t stream, Launch&& launch) {
-  if (!g_prof_on) {
-    launch();
-    return hipGetLastError();
-  }
-  hipEvent_t e0, e1;
-  {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    e0 = prof_event();
-    e1 = prof_event();
-  }
-  (void)hipEventRecord(e0, stream);
+  const ProfTicket t = prof_begin(stream);
   launch();
-  hipError_t err = hipGetLastError();
-  (void)hipEventRecord(e1, stream);
-  {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfClass& c = g_prof[name];
-    c.flops += 2.0 * a.M * a.Cin * a.K * (double)a.L * a.B;     // algorithmic: dense over every position
-    // every input and output element once, fp32: rows * L outputs (half of that after the gate), residual and
-    // accumulated-output reads where the epilogue has them, the packed weights once
-    const double outs = (gate ? 0.5 : 1.0) * a.M;
-    const int reads = ((a.flags & (F_RES | F_RES_SUB)) ? 1 : 0) + ((a.flags & F_ACCUM) ? 1 : 0);
-    const double wbytes = strstr(name, "conv_mfma") || strstr(name, "conv_f16x2") || strstr(name, "resblock_pair") ? 4.0
-                          : strstr(name, "conv_bf16_kernel") ? 2.0 : 6.0;
-    const double sb = strstr(name, "conv_bf16_kernel") ? 2.0 : 4.0;           // bytes per staged element
-    const double in_b = (a.flags & F_IN_STAGED) ? sb : 4.0, out_b = (a.flags & F_OUT_STAGED) ? sb : 4.0;
-    c.bytes += (double)a.L * a.B * (in_b * a.Cin + outs * (out_b + 4.0 * reads + (a.out2 ? 4.0 : 0.0))) + wbytes * a.M * a.Cin * a.K;
-    c.count += 1;
-    c.pending.emplace_back(e0, e1);
-  }
+  const hipError_t err = hipGetLastError();
+  prof_end(t, name, gate, a, stream);
   return err;
 }
 
@@ -1759,6 +1767,11 @@ static bool try_launch_gl(ConvArgs& a, hipStream_t stream, hipError_t& err) {
     return e && e[0] ? atoll(e) : -1LL;
   }();
   if (blocks_of(wide || !tall ? 256 : 128) <= (min_blocks >= 0 ? min_blocks : slots / 2)) return false;
+  // 7 and 11 taps: the 16 x 16 x 32 build
+  if (conv_gl16_takes(a)) {
+    err = launch_conv_gl16(a, wide, tall, stream);
+    return true;
+  }
   // look-ahead D steps; the activation tile goes out A chunks ahead with A * K >= D
   if (wide)
     err = a.K == 3 ? launch_gl_cfg<4, 2, 2, 3, 3, 1>(a, stream) : a.K == 7 ? launch_gl_cfg<4, 2, 2, 7, 3, 1>(a, stream)
