@@ -39,6 +39,8 @@ typedef struct vits_config {
   int n_upsamples;
   int upsample_rates[8], upsample_kernel_sizes[8], upsample_initial_channel;
   int n_resblock_kernels, resblock_kernel_sizes[8], n_resblock_dilations, resblock_dilation_sizes[8][8];
+  int resblock;   /* 1: modules.ResBlock1 (pairs of convs, reference modules.py:183-225); 2: modules.ResBlock2 (single
+                   * convs, modules.py:228-252); 0 is read as 1 */
 } vits_config;
 
 const char* vits_last_error(void);

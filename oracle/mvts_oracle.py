@@ -50,10 +50,11 @@ class OracleSynthesizer:
     def __init__(self, state_dict: Dict[str, torch.Tensor], n_heads: int = 2, window: int = 4,
                  upsample_rates=(8, 8, 4, 2), upsample_kernel_sizes=(16, 16, 4, 4),
                  resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3, 5),) * 3,
-                 kernel_size: int = 3, n_speakers: int = 200, generator_bf16: bool = False):
+                 kernel_size: int = 3, n_speakers: int = 200, generator_bf16: bool = False, resblock: str = "1"):
         # generator_bf16: emulate the build's "bf16" conv mode -- both operands of every MFMA conv of the generator
         # (conv_pre, ups, ResBlock convs; not conv_post) rounded to nearest-even bf16, products accumulated in fp32
         self.generator_bf16 = generator_bf16
+        self.resblock = str(resblock)             # "1": modules.ResBlock1, "2": modules.ResBlock2
         sd = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}
         w: Dict[str, torch.Tensor] = {}
         for k, v in sd.items():
@@ -271,6 +272,11 @@ class OracleSynthesizer:
                 y = x
                 for n, d in enumerate(self.rb_d[j]):
                     t = F.leaky_relu(y, LRELU_SLOPE)
+                    if self.resblock == "2":             # modules.ResBlock2 (reference modules.py:241-250): x = c(lrelu(x)) + x
+                        t = F.conv1d(q(t), q(w[f"dec.resblocks.{r}.convs.{n}.weight"]),
+                                     w[f"dec.resblocks.{r}.convs.{n}.bias"], padding=(k * d - d) // 2, dilation=d)
+                        y = t + y
+                        continue
                     t = F.conv1d(q(t), q(w[f"dec.resblocks.{r}.convs1.{n}.weight"]),
                                  w[f"dec.resblocks.{r}.convs1.{n}.bias"], padding=(k * d - d) // 2, dilation=d)
                     t = F.leaky_relu(t, LRELU_SLOPE)

@@ -372,6 +372,25 @@ def test_generator_chain_with_unfusable_pair(synthetic_sd):
     assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= MEL_TOL
 
 
+def test_infer_resblock2_generator():
+    """resblock "2" (modules.ResBlock2, reference modules.py:228-252: one conv per dilation, x = c(leaky_relu(x)) + x):
+    against vectors of the reference built with that option, and streaming windows against the whole utterance."""
+    from golden_util import infer_kwargs, load_case
+    cfg = synthetic.ModelConfig(resblock="2", resblock_dilation_sizes=((1, 3), (1, 3), (1, 3)))
+    sd = synthetic.synthetic_state_dict(cfg, include_enc_q=False)
+    net = _model(sd, cfg=cfg)
+    d, meta = load_case("resblock2_b2")
+    kw = infer_kwargs(d, meta)
+    o, x_mask, (z, *_), *_ = net.infer(d["in_phonemes"], d["in_lengths"], sid=d["in_sid"], noise=d["out_noise"], **kw)
+    assert torch.equal(x_mask.cpu(), d["out_x_mask"])
+    assert metrics.max_abs(z, d["out_z"]) <= LATENT_TOL
+    assert o.shape == d["out_o"].shape and metrics.max_abs(o, d["out_o"]) <= WAV_TOL
+    assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= MEL_TOL
+    st = net.infer_stream(d["in_phonemes"], d["in_lengths"], sid=d["in_sid"], noise=d["out_noise"], chunk_frames=16, **kw)
+    assert st.halo_frames == 8
+    assert metrics.max_abs(torch.cat([w for _, w in st], -1), o) <= STREAM_TOL
+
+
 def test_infer_long_utterance_beyond_2048_frames(gpu_model, oracle_model):
     """An utterance of 2600 frames (30 s): past the 2048 positions the lanes-on-keys attention kernel can hold, the
     frame-rate encoder runs on the matrix-core attention kernel, which walks the keys in tiles and has no such bound.

@@ -183,6 +183,10 @@ def test_generator_halo_frames():
     import dataclasses
     wide = dataclasses.replace(cfg, resblock_kernel_sizes=(3, 7, 13))
     assert generator_halo_frames(wide) > 13
+    # modules.ResBlock2: one conv per dilation, no second undilated conv -- 20 samples per stage for kernel 11 with
+    # dilations (1, 3): 23 -> 13 -> 33 -> 10 -> 30 -> 5 -> 25 -> 5 -> 8 frames
+    single = dataclasses.replace(cfg, resblock="2", resblock_dilation_sizes=((1, 3),) * 3)
+    assert generator_halo_frames(single) == 8
 
 
 def _cpu_model(monkeypatch):

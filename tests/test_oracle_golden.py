@@ -56,6 +56,26 @@ def test_oracle_matches_reference(oracle_model, name):
     assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= 1e-4
 
 
+RESBLOCK2 = dict(resblock="2", resblock_dilation_sizes=((1, 3), (1, 3), (1, 3)))
+
+
+def test_oracle_matches_reference_resblock2():
+    """The generator variant built from modules.ResBlock2 (reference modules.py:228-252; resblock "2"): vectors from
+    the reference constructed with that option and the synthetic checkpoint of the same configuration."""
+    from oracle.mvts_oracle import OracleSynthesizer
+    cfg = synthetic.ModelConfig(**RESBLOCK2)
+    manifest = synthetic.state_dict_manifest(cfg)
+    assert "dec.resblocks.0.convs.1.weight_v" in manifest and "dec.resblocks.0.convs1.0.weight_v" not in manifest
+    sd = synthetic.synthetic_state_dict(cfg, include_enc_q=False)
+    orc = OracleSynthesizer(sd, resblock="2", resblock_dilation_sizes=RESBLOCK2["resblock_dilation_sizes"])
+    d, meta = load_case("resblock2_b2")
+    o, x_mask, (z, *_), *_ = orc.infer(d["in_phonemes"], d["in_lengths"], sid=d["in_sid"], noise=d["out_noise"],
+                                       **infer_kwargs(d, meta))
+    assert torch.equal(x_mask, d["out_x_mask"])
+    assert metrics.max_abs(z, d["out_z"]) <= TOL and metrics.max_abs(o, d["out_o"]) <= TOL
+    assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= 1e-4
+
+
 def test_oracle_c1_fullsize(oracle_model):
     b = synthetic.config_c1()
     z = np.load(os.path.join(GOLDEN, "c1.npz"))

@@ -37,10 +37,12 @@ from oracle import metrics  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
-def load_reference():
+def load_reference(**model_overrides):
     raw = open(os.path.join(REF, "configs/config.json"), "rb").read().decode("gbk")
     raw = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", raw, flags=re.S))
-    hps = utils.HParams(**json.loads(raw))
+    cfg_json = json.loads(raw)
+    cfg_json["model"].update(model_overrides)
+    hps = utils.HParams(**cfg_json)
     net = models.SynthesizerTrn(len(symbols), hps.data.filter_length // 2 + 1, hps.data.hop_length,
                                 hps.data.sampling_rate, hps.train.segment_size // hps.data.hop_length,
                                 n_speakers=hps.data.n_speakers, **hps.model).eval()
@@ -117,9 +119,47 @@ def make_vc(net, oracle, report):
                         out_z_p=to_np(z_p), out_z_hat=to_np(z_hat))
 
 
+RESBLOCK2 = dict(resblock="2", resblock_dilation_sizes=((1, 3), (1, 3), (1, 3)))
+
+
+def make_resblock2(report):
+    """The reference built with modules.ResBlock2 (resblock "2", two dilations per kernel size; everything else as in
+    configs/config.json): one ragged batch, waveform and latents."""
+    cfg = synthetic.ModelConfig(**RESBLOCK2)
+    net, _ = load_reference(resblock="2", resblock_dilation_sizes=[list(d) for d in RESBLOCK2["resblock_dilation_sizes"]])
+    manifest = synthetic.state_dict_manifest(cfg)
+    ref_sd = net.state_dict()
+    assert list(manifest.keys()) == list(ref_sd.keys()), "ResBlock2 manifest order/names differ from the reference"
+    for k, shp in manifest.items():
+        assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
+    sd = synthetic.synthetic_state_dict(cfg)
+    net.load_state_dict(sd, strict=True)
+    oracle = OracleSynthesizer(sd, resblock="2", resblock_dilation_sizes=RESBLOCK2["resblock_dilation_sizes"])
+    b = synthetic.make_batch(17, [13, 8], [42, 27])
+    kw = dict(noise_scale=0.667, duration_control=b.durations)
+    stages = {}
+    ref = run_reference(net, b, 1717, stages, **kw)
+    orc = oracle.infer(b.phonemes, b.lengths, sid=b.sid, noise=ref["noise"], **kw)
+    errs = {"o": metrics.max_abs(orc[0], ref["o"]), "z": metrics.max_abs(orc[2][0], ref["z"])}
+    report["cases"]["resblock2_b2"] = dict(oracle_vs_reference_max_abs=errs, wav_std=float(ref["o"].std()),
+                                           wav_absmax=float(ref["o"].abs().max()))
+    print("resblock2_b2", json.dumps(report["cases"]["resblock2_b2"]))
+    np.savez_compressed(os.path.join(OUT, "resblock2_b2.npz"), in_phonemes=to_np(b.phonemes), in_lengths=to_np(b.lengths),
+                        in_sid=to_np(b.sid), in_duration_control=to_np(b.durations), out_noise=to_np(ref["noise"]),
+                        out_o=to_np(ref["o"]), out_z=to_np(ref["z"]), out_x_mask=to_np(ref["x_mask"]),
+                        meta_json=np.frombuffer(json.dumps(dict(noise_scale=0.667)).encode(), dtype=np.uint8))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cfg = synthetic.ModelConfig()
+    if "--resblock2-only" in sys.argv:   # add / refresh the ResBlock2 vectors without touching the others
+        path = os.path.join(OUT, "ORACLE_VS_REFERENCE.json")
+        report = json.load(open(path))
+        make_resblock2(report)
+        with open(path, "w") as f:
+            json.dump(report, f, indent=1)
+        return
     net, hps = load_reference()
     if "--vc-only" in sys.argv:          # add / refresh the voice-conversion vectors without touching the others
         sd = synthetic.synthetic_state_dict(cfg)
@@ -216,6 +256,7 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **{k: to_np(v) for k, v in arrays.items()})
 
     make_vc(net, oracle, report)
+    make_resblock2(report)
 
     # (vi) full-size C1 / C2: every 97th sample, digest, log-mel summary
     for name, batch in (("c1", synthetic.config_c1()), ("c2", synthetic.config_c2())):

@@ -26,6 +26,7 @@ class VitsConfig(C.Structure):
         ("upsample_initial_channel", C.c_int),
         ("n_resblock_kernels", C.c_int), ("resblock_kernel_sizes", C.c_int * 8),
         ("n_resblock_dilations", C.c_int), ("resblock_dilation_sizes", (C.c_int * 8) * 8),
+        ("resblock", C.c_int),
     ]
 
 

@@ -185,6 +185,8 @@ __device__ __forceinline__ void epilogue16(const ConvArgs& a, f32x4 (&acc)[4][NT
   }
 }
 
+}  // namespace
+
 // S: ring slots of one flat step's weights each (even; the look-ahead is (S - 2) / 2 pair steps).
 template <int WN, int WGM, int WGN, int K, int S>
 __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
@@ -425,6 +427,8 @@ __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
 
   epilogue16<NT>(a, acc, (mt0 + wm * 2) * 32, t0 + wn * 32 * WN, lane, b);
 }
+
+namespace {
 
 bool gl16_enabled() {
   static const bool on = [] {

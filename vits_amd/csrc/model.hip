@@ -350,8 +350,8 @@ int vits_model_create(const vits_config* cfg, vits_model** out) {
   if (c.n_flows <= 0 || c.n_flows % 2) return fail(VITS_ERR_INVALID, "n_flows must be even (channel flips are folded into weights)");
   if ((c.inter_channels / 2) % CI_CHUNK) return fail(VITS_ERR_INVALID, "inter_channels / 2 must be a multiple of 16");
   if (c.n_upsamples <= 0 || c.n_upsamples > 8 || c.n_resblock_kernels <= 0 || c.n_resblock_kernels > 8 ||
-      c.n_resblock_dilations <= 0 || c.n_resblock_dilations > 8)
-    return fail(VITS_ERR_INVALID, "generator: bad upsample / resblock counts");
+      c.n_resblock_dilations <= 0 || c.n_resblock_dilations > 8 || c.resblock < 0 || c.resblock > 2)
+    return fail(VITS_ERR_INVALID, "generator: bad upsample / resblock counts or resblock type");
   if (c.gin_channels <= 0 || c.n_speakers <= 1) return fail(VITS_ERR_INVALID, "a speaker-conditioned model is required (n_speakers > 1, gin_channels > 0)");
   for (int i = 0; i < c.n_upsamples; ++i) {
     const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
@@ -529,6 +529,7 @@ int vits_model_finalize(vits_model* m) {
       const std::string p = "dec.rb." + std::to_string(i * c.n_resblock_kernels + j);
       for (int q = 0; q < c.n_resblock_dilations; ++q) {
         rb.c1.push_back(need_conv(m, p + ".c1." + std::to_string(q), cout, cout, c.resblock_kernel_sizes[j], MODE_PLAIN, miss));
+        if (c.resblock == 2) continue;             // modules.ResBlock2: one conv per dilation
         rb.c2.push_back(need_conv(m, p + ".c2." + std::to_string(q), cout, cout, c.resblock_kernel_sizes[j], MODE_PLAIN, miss));
       }
       m->rbs.push_back(rb);
@@ -1020,7 +1021,8 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
     // split into fp16 h / l) -- x is converted once for all chains here, and the second conv of a pair writes its
     // result twice, as fp32 (the residual of the next pair) and staged (the input of the next pair's first conv).
     bool stage_x = false;
-    for (int j = 0; j < nk && staged_pairs_enabled(); ++j) {
+    const bool single = c.resblock == 2;            // modules.ResBlock2 (reference modules.py:228-252)
+    for (int j = 0; j < nk && staged_pairs_enabled() && !single; ++j) {
       const ResBlock& rb = m->rbs[i * nk + j];
       bool fused = fused_pairs_enabled();
       for (int q = 0; q < nd && fused; ++q) fused = pair_profitable(rb.c1[q], rb.c2[q]);
@@ -1044,9 +1046,20 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
       // it cannot run in place) while the two-launch pair keeps T for the tensor between its convs and updates Y in
       // place; a chain that mixed the two would hand a fused pair's output in T to a two-launch pair that overwrites
       // T before reading it.  So a chain is fused only when every one of its pairs is.
-      bool fuse_chain = fused_pairs_enabled();
+      bool fuse_chain = fused_pairs_enabled() && !single;
       for (int q = 0; q < nd && fuse_chain; ++q) fuse_chain = pair_profitable(rb.c1[q], rb.c2[q]);
       for (int q = 0; q < nd; ++q) {
+        if (single) {
+          // x = c(leaky_relu(x)) + x per dilation; the carrier alternates between Y and T because a conv with a halo
+          // cannot update its own input, and the last conv adds the chain into the sum of the stage
+          const bool last = q + 1 == nd;
+          float* dst = last ? XS : ((q & 1) ? Tt[j] : Y[j]);
+          if (last && j > 0 && n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
+          TRY(conv_simple(rb.c1[q], yin, dst, B, L, nullptr, F_IN_LRELU | F_RES | (last && j > 0 ? F_ACCUM : 0), sj, yin,
+                          nullptr, 0, nullptr, 0, 1.f, 0.1f, 0.1f));
+          yin = dst;
+          continue;
+        }
         if (fuse_chain) {
           // the whole pair in one launch, the tensor between the convs never leaves LDS; Y and T take turns as the
           // chain's carrier

@@ -33,8 +33,8 @@ class SynthesizerTrn:
                  resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates, upsample_initial_channel,
                  upsample_kernel_sizes, n_speakers=0, gin_channels=0, use_sdp=False, freeze_textencoder=False,
                  freeze_decoder=False, **kwargs):
-        if str(resblock) != "1":
-            raise NotImplementedError("only resblock='1' (ResBlock1) is implemented; the reference config uses it")
+        if str(resblock) not in ("1", "2"):
+            raise ValueError("resblock must be '1' (modules.ResBlock1) or '2' (modules.ResBlock2)")
         if n_speakers <= 1 or gin_channels <= 0:
             raise NotImplementedError("a speaker-conditioned model (n_speakers > 1, gin_channels > 0) is required")
         # arithmetic of the conv kernels.  fp32-grade: "f16x2" (default: the generator's convs as three fp16 products
@@ -86,6 +86,7 @@ class SynthesizerTrn:
         for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
             c.upsample_rates[i], c.upsample_kernel_sizes[i] = u, k
         c.upsample_initial_channel = cfg.upsample_initial_channel
+        c.resblock = int(cfg.resblock)
         c.n_resblock_kernels = len(cfg.resblock_kernel_sizes)
         for j, k in enumerate(cfg.resblock_kernel_sizes):
             c.resblock_kernel_sizes[j] = k
@@ -594,7 +595,8 @@ def config_from_hparams(hps, n_vocab: int):
 # 63 -> 33 -> 93 -> 25 -> 85 -> 12 -> 72 -> 10 -> 13 frames.  InferStream computes it from the model's own configuration.
 def generator_halo_frames(cfg) -> int:
     reach = 3                                                     # conv_post, kernel 7
-    per_stage = max(sum((k - 1) * d // 2 + (k - 1) // 2 for d in dils)
+    second = 0 if str(cfg.resblock) == "2" else 1                 # ResBlock2 has no second, undilated conv per dilation
+    per_stage = max(sum((k - 1) * d // 2 + second * ((k - 1) // 2) for d in dils)
                     for k, dils in zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes))
     for u in reversed(cfg.upsample_rates):
         reach = -(-(reach + per_stage) // u) + 1

@@ -132,7 +132,7 @@ def state_dict_manifest(cfg: ModelConfig = ModelConfig()) -> "OrderedDict[str, T
         ch = ch0 // 2 ** (i + 1)
         for j, (rk, rd) in enumerate(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes)):
             r = i * n_k + j
-            for grp in ("convs1", "convs2"):
+            for grp in (("convs",) if str(cfg.resblock) == "2" else ("convs1", "convs2")):
                 for q in range(len(rd)):
                     p = f"dec.resblocks.{r}.{grp}.{q}"
                     m += [(f"{p}.bias", (ch,)), (f"{p}.weight_g", (ch, 1, 1)), (f"{p}.weight_v", (ch, ch, rk))]

@@ -247,6 +247,10 @@ def prepare(sd: Dict[str, torch.Tensor], cfg, precision: int = N.PREC_F32) -> Pr
         for j, dils in enumerate(cfg.resblock_dilation_sizes):
             r = i * n_k + j
             for q, dil in enumerate(dils):
+                if str(cfg.resblock) == "2":                    # modules.ResBlock2: one conv per dilation
+                    pw.add_conv(f"dec.rb.{r}.c1.{q}", folded(sd, f"dec.resblocks.{r}.convs.{q}"),
+                                bias(f"dec.resblocks.{r}.convs.{q}"), dilation=dil)
+                    continue
                 pw.add_conv(f"dec.rb.{r}.c1.{q}", folded(sd, f"dec.resblocks.{r}.convs1.{q}"),
                             bias(f"dec.resblocks.{r}.convs1.{q}"), dilation=dil)
                 pw.add_conv(f"dec.rb.{r}.c2.{q}", folded(sd, f"dec.resblocks.{r}.convs2.{q}"),
