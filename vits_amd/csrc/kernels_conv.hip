@@ -2313,8 +2313,8 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
 // Fused ResBlock pair for the 32-channel stage (PREC_F16X2): out = x + c2(lrelu(c1(lrelu(x)))) (+ out).
 // The stage is bandwidth-bound, and the unfused pair moves five tensor passes (x in, t out, t in, x in again, out);
 // here a block computes c1 on 256 time steps into LDS (leaky-relu'd, split into fp16 h / l, in c2's operand layout,
-// zero outside the sequence as c2's padding requires) and c2 on the inner 224 of them, so x is read once (plus halo)
-// and only the result is written.  Same accumulation order per output as the two separate kernels: bit-identical.
+// zero outside the sequence as c2's padding requires) and c2 on the inner 224 of them, so x is read once (plus halo;
+// the raw values of the block's own columns stay in registers and are the residual) and only the result is written.  Same accumulation order per output as the two separate kernels: bit-identical.
 //   block = 4 waves side by side in time; c1: wave tile 32 rows x 64 steps; c2: n-tiles 2w, 2w + 1 of the 7 valid ones.
 //   Y column c <-> time t0 - 16 + c;  c2 output column o <-> time t0 + o, reads Y columns o + 16 + k - (K-1)/2.
 // ---------------------------------------------------------------------------------------------------------
@@ -2335,7 +2335,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
                                                                const float* __restrict__ b2, int dil) {
   constexpr int WGN = 4 / MT, W1 = 64 * WGN, BN = W1 - 32, NCH = 2 * MT;
   constexpr int NT = NCH * K, D = PAIR_AHEAD;               // taps per conv; depth of the weight ring
-  constexpr int NCT = (W1 + 50 + 255) / 256;                // x-tile columns per thread
+  constexpr int OP = BN + 8;                                // row pitch of the result tile in LDS (floats)
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2344,55 +2344,69 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
   const int b = blockIdx.z, t0 = blockIdx.x * BN;
   const int h1 = (K - 1) / 2 * dil, h2 = (K - 1) / 2;
   const int ncols = W1 + 2 * h1;                            // x tile: times t0 - 16 - h1 ... , one column per time step
-  uint4* xq = lds;                                          // [2 planes][2 halves][ncols]
+  uint4* xq = lds;                                          // [2 planes][2 halves][ncols]: one 16-channel chunk at a time
   uint4* yq = lds + 4 * ncols;                              // [NCH chunks][2 planes][2 halves][W1] (+ slack)
   const float* xb = a.x + (long long)b * a.x_bs;
   const int tx0 = t0 - PAIR_YOFF - h1;
 
-  float st[NCT][16];
-  auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+  // The whole x tile is requested at once, before anything else: one memory round trip per block instead of one per
+  // chunk plus one for the residual.
+  //   * thread (c, cp) = (tid % W1, tid / W1) owns tile column c + h1 (time t0 - 16 + c: the W1 columns under the first
+  //     conv's outputs, which include every column the block writes) for the chunks 2 cp, 2 cp + 1: 32 raw values that
+  //     stay in registers to the end -- they are the residual of the block's own outputs, so x is never read twice;
+  //   * the 2 * h1 halo columns on either side: thread tid < 2 * h1 * NCH takes (column, chunk) item tid.
+  const int oc = tid % W1, ocp = tid / W1;
+  const int ot = t0 - PAIR_YOFF + oc;                       // this thread's own column: its time step
+  const bool o_ok = ot >= 0 && ot < a.L;
+  const int nh = 2 * h1 * NCH;                              // halo items
+  const int hidx = tid / NCH, hch = tid % NCH;              // this thread's halo item: column index, chunk
+  const int hcol = hidx < h1 ? hidx : W1 + hidx;            // tile column: left halo [0, h1), right halo [W1 + h1, ncols)
+  const int ht = tx0 + hcol;
+  const bool h_has = tid < nh, h_ok = h_has && ht >= 0 && ht < a.L;
+  float st[2][16], sb[16];
+  {
+    const float* xo = xb + (long long)(ocp * 32) * a.x_cs + (o_ok ? ot : 0);
 #pragma unroll
-    for (int q = 0; q < NCT; ++q) {
-      const int col = tid + 256 * q, t = tx0 + col;
-      if (col - lane >= ncols) continue;               // none of this wave's columns is in the tile: no requests
-      const bool ok = col < ncols && t >= 0 && t < a.L;
-      const float* xc = xb + (long long)chunk * 16 * a.x_cs + (ok ? t : 0);
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int ci = 0; ci < 16; ++ci) st[q][ci] = xc[(long long)ci * a.x_cs];
+      for (int ci = 0; ci < 16; ++ci) st[u][ci] = xo[(long long)(u * 16 + ci) * a.x_cs];
+    const float* xh = xb + (long long)(hch * 16) * a.x_cs + (h_ok ? ht : 0);
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci) sb[ci] = h_has ? xh[(long long)ci * a.x_cs] : 0.f;
+  }
+  // 16 channels of one tile column -> leaky-relu, clamp, split into fp16 h / l, four 16-byte units of xq
+  auto put = [&](const float (&v16)[16], int col, bool ok) __attribute__((always_inline)) {
+    unsigned ph[8], pl[8];
+    float amax = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < 8; ++c2) {
+      f32x2 v;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float e = v16[2 * c2 + u];
+        e = fmaxf(e, e * a.slope);
+        amax = fmaxf(amax, fabsf(e));
+        e = fminf(fmaxf(e, -65504.f), 65504.f);
+        v[u] = ok ? e : 0.f;
+      }
+      const f16x2 h = __builtin_convertvector(v, f16x2);
+      const f16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), f16x2);
+      ph[c2] = __builtin_bit_cast(unsigned, h);
+      pl[c2] = __builtin_bit_cast(unsigned, l);
+    }
+    if (ok) report_f16_range(a.range_flag, amax);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      xq[(0 * 2 + hf) * ncols + col] = make_uint4(ph[4 * hf], ph[4 * hf + 1], ph[4 * hf + 2], ph[4 * hf + 3]);
+      xq[(1 * 2 + hf) * ncols + col] = make_uint4(pl[4 * hf], pl[4 * hf + 1], pl[4 * hf + 2], pl[4 * hf + 3]);
     }
   };
-  auto store_chunk = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < NCT; ++q) {
-      const int col = tid + 256 * q, t = tx0 + col;
-      if (col < ncols) {
-        const bool ok = t >= 0 && t < a.L;
-        unsigned ph[8], pl[8];
-        float amax = 0.f;
-#pragma unroll
-        for (int c2 = 0; c2 < 8; ++c2) {
-          f32x2 v;
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            float e = st[q][2 * c2 + u];
-            e = fmaxf(e, e * a.slope);
-            amax = fmaxf(amax, fabsf(e));
-            e = fminf(fmaxf(e, -65504.f), 65504.f);
-            v[u] = ok ? e : 0.f;
-          }
-          const f16x2 h = __builtin_convertvector(v, f16x2);
-          const f16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), f16x2);
-          ph[c2] = __builtin_bit_cast(unsigned, h);
-          pl[c2] = __builtin_bit_cast(unsigned, l);
-        }
-        report_f16_range(a.range_flag, amax);
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          xq[(0 * 2 + hf) * ncols + col] = make_uint4(ph[4 * hf], ph[4 * hf + 1], ph[4 * hf + 2], ph[4 * hf + 3]);
-          xq[(1 * 2 + hf) * ncols + col] = make_uint4(pl[4 * hf], pl[4 * hf + 1], pl[4 * hf + 2], pl[4 * hf + 3]);
-        }
-      }
+  auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
+    if ((chunk >> 1) == ocp) {
+      if (chunk & 1) put(st[1], oc + h1, o_ok);
+      else put(st[0], oc + h1, o_ok);
     }
+    if (h_has && hch == chunk) put(sb, hcol, h_ok);
   };
 
   f32x16 acc[2];
@@ -2423,24 +2437,6 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
 
   // ---- first conv: rows 32 * wm .., Y columns [64 * wn, 64 * wn + 64) ----
   zero_acc();
-  load_chunk(0);
-  // The residual (x at this lane's output positions) is fetched as soon as the staging registers are free (after the
-  // last chunk of the x tile has gone to LDS), while the tile's cache lines are still in L2, and held in registers to
-  // the end: by the epilogue those lines have long been evicted and the second read of x went to memory again
-  // (measured: 270 MB of 970 MB per launch).
-  float rv[2][16];
-  auto load_residual = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int t = t0 + wn * 64 + j * 32 + l31;
-      const int tc = t < a.L ? t : a.L - 1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        rv[j][r] = xb[(long long)(32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)) * a.x_cs + tc];
-    }
-  };
-  store_chunk();
-  __syncthreads();
   {
     const int colbase = wn * 64 + l31 + par * ncols;
     auto taps = [&](int chunk) __attribute__((always_inline)) {
@@ -2462,15 +2458,12 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
       }
     };
 #pragma unroll
-    for (int chunk = 0; chunk + 1 < NCH; ++chunk) {
-      load_chunk(chunk + 1);
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+      if (chunk > 0) __syncthreads();                      // every wave has read the previous chunk
+      store_chunk(chunk);
+      __syncthreads();
       taps(chunk);
-      __syncthreads();
-      store_chunk();
-      __syncthreads();
     }
-    load_residual();                                       // the staging registers are free from here on
-    taps(NCH - 1);
   }
   // ---- Y = split(lrelu(c1 + bias)), zero outside the sequence; 8-byte pieces (four channels of a half) ----
   {
@@ -2533,34 +2526,43 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
         fetch_a(g + D);
       }
   }
-  // ---- out = c2 + bias + x (+ out); all loads of the tile before its first store ----
+  // ---- out = c2 + bias + x (+ out) ----
+  // The result goes through LDS (the Y tile is dead once every wave has finished the second conv) into the layout
+  // the x tile was loaded in: thread (c, cp) takes column o = c - 16 of its 32 rows, adds the raw x it has kept since
+  // the load, and stores runs of 64 consecutive time steps per row.  Same operations in the same order as an epilogue
+  // in the accumulator layout: c2 + bias, + x, + out.
   {
     float* ob = a.out + (long long)b * a.out_bs;
-    float bz[16], ov[2][16];
+    const int o = oc - PAIR_YOFF, t = t0 + o;
+    const bool mine = o >= 0 && o < BN && t < a.L;
+    float ov[32];
+    if (a.accumulate) {                                    // requested before the barriers below
+      const int tc = mine ? t : 0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) ov[i] = ob[(long long)(32 * ocp + i) * a.out_cs + tc];
+    }
+    float bz[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bz[r] = b2 ? b2[32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+    __syncthreads();                                       // every wave has read its last Y fragment
+    float* oq = reinterpret_cast<float*>(yq);              // [32 * MT rows][OP]
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int o = wn * 64 + j * 32 + l31, t = t0 + o;
-      const int tc = t < a.L ? t : a.L - 1;
+      const int col = wn * 64 + j * 32 + l31;
+      if (col < BN) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wm + 4 * par + (r & 3) + 8 * (r >> 2);
-        ov[j][r] = a.accumulate ? ob[(long long)row * a.out_cs + tc] : 0.f;
+        for (int r = 0; r < 16; ++r)
+          oq[(32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)) * OP + col] = acc[j][r] + bz[r];
       }
     }
+    __syncthreads();
+    if (mine) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int o = wn * 64 + j * 32 + l31, t = t0 + o;
-      if (o < BN && t < a.L) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 32 * wm + 4 * par + (r & 3) + 8 * (r >> 2);
-          float v = acc[j][r] + bz[r];
-          v += rv[j][r];
-          if (a.accumulate) v += ov[j][r];
-          ob[(long long)row * a.out_cs + t] = v;
-        }
+      for (int i = 0; i < 32; ++i) {
+        float v = oq[(32 * ocp + i) * OP + o];
+        v += st[i >> 4][i & 15];
+        if (a.accumulate) v += ov[i];
+        ob[(long long)(32 * ocp + i) * a.out_cs + t] = v;
       }
     }
   }
