@@ -93,7 +93,19 @@ struct ConvArgs {
   const float* ln_in_stats; const float* ln_in_gamma; const float* ln_in_beta;
   const float* ln_res_stats; const float* ln_res_gamma; const float* ln_res_beta;
   float* ln_out_stats;
+  int xcd_map;                                        // launch_conv: blockIdx.x -> time tile goes through xcd_tile()
 };
+
+// Which time tile the block with blockIdx.x = bx of a row of ntiles blocks takes.  Workgroups go to the chip's eight
+// XCDs round-robin in launch order, and each XCD has its own L2: with the identity mapping the neighbours of a tile --
+// which read the same halo columns and the other halves of its cache lines -- always sit on other XCDs, and every one
+// of them fetches those lines from memory again.  Here the blocks an XCD receives (bx = f, f + 8, f + 16, ...) take
+// consecutive tiles, so neighbouring tiles share an L2 and run at about the same time.  A bijection for any ntiles.
+__device__ __forceinline__ int xcd_tile(int bx, int ntiles, int on) {
+  if (!on || ntiles < 16) return bx;
+  const int f = bx & 7, q = ntiles >> 3, r = ntiles & 7;
+  return f * q + (f < r ? f : r) + (bx >> 3);
+}
 
 // mean and 1 / sqrt(var + eps) of one time step from the per-unit partial statistics (Chan's combination of
 // (sum, M2) pairs over units of 64 channels)
@@ -123,7 +135,9 @@ struct PairArgs {
   int accumulate;                // out += result (read-modify-write)
   float slope;                   // leaky-relu slope before both convs
   int* range_flag = nullptr;     // OR 1 into it when an activation was clamped to the fp16 range (null: not reported)
+  int xcd_map = 0;               // launch_resblock_pair: blockIdx.x -> time tile goes through xcd_tile()
 };
+bool xcd_map_enabled();          // VITS_XCD_MAP=0 switches the mapping off (A/B measurements)
 bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2);       // the kernel supports the shape (32 or 64 channels)
 bool pair_profitable(const ConvDesc& c1, const ConvDesc& c2);    // ... and is the faster choice for it
 hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const PairArgs& a, hipStream_t stream);

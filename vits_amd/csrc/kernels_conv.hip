@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
   const int wm = wave / WGN, wn = wave % WGN;
   const int par = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z;
-  const int t0 = blockIdx.x * BN;
+  const int t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
   const int len_b = a.lengths ? a.lengths[b] : 0x7fffffff;
   const int rs = a.rs;
 
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
   const int wm = wave / WGN, wn = wave % WGN;
   const int par = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z;
-  const int t0 = blockIdx.x * BN;
+  const int t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
   const int len_b = a.lengths ? a.lengths[b] : 0x7fffffff;
   const int ncols = a.rs;
 
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
   const int wm = wave / WGN, wn = wave % WGN;
   const int par = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z;
-  const int t0 = blockIdx.x * BN;
+  const int t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
   const int len_b = a.lengths ? a.lengths[b] : 0x7fffffff;
   const int ncols = a.rs;
 
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
   const int wm = wave / WGN, wn = wave % WGN;
   const int par = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z;
-  const int t0 = blockIdx.x * BN;
+  const int t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
   const int len_b = a.lengths ? a.lengths[b] : 0x7fffffff;
   const int ncols = a.rs;
 
@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(256, 2) void conv_gl_kernel(const ConvArgs a) {
   const int wm = wave / WGN, wn = wave % WGN;
   const int par = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z;
-  const int t0 = blockIdx.x * BN;
+  const int t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
   const int mt0 = blockIdx.y * (BM / 32);
   int mt[WM];
   bool mt_ok[WM];
@@ -2105,6 +2105,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : WN <= 2 ? 2 : 1) void conv_b
   }
 }
 
+bool xcd_map_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_XCD_MAP");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 int device_cu_count() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -2240,6 +2248,7 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   if (a.B > 65535) return hipErrorInvalidValue;
   a.w = d.w;
   a.bias = d.bias;
+  a.xcd_map = xcd_map_enabled();
   a.Cin = d.Cin;
   a.M = d.M;
   a.K = d.K;
@@ -2341,7 +2350,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
   const int par = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.z, t0 = blockIdx.x * BN;
+  const int b = blockIdx.z, t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
   const int h1 = (K - 1) / 2 * dil, h2 = (K - 1) / 2;
   const int ncols = W1 + 2 * h1;                            // x tile: times t0 - 16 - h1 ... , one column per time step
   uint4* xq = lds;                                          // [2 planes][2 halves][ncols]: one 16-channel chunk at a time
@@ -2604,8 +2613,10 @@ hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const Pa
   snprintf(name, sizeof name, "resblock_pair_kernel<%d,%d>", MT, K);
   const uint4* w1 = reinterpret_cast<const uint4*>(c1.w);
   const uint4* w2 = reinterpret_cast<const uint4*>(c2.w);
+  PairArgs pa = a;
+  pa.xcd_map = xcd_map_enabled();
   auto go = [&](auto mt, auto kk) {
-    hipLaunchKernelGGL((resblock_pair_kernel<decltype(mt)::value, decltype(kk)::value>), grid, dim3(256), lds, stream, a,
+    hipLaunchKernelGGL((resblock_pair_kernel<decltype(mt)::value, decltype(kk)::value>), grid, dim3(256), lds, stream, pa,
                        w1, c1.bias, w2, c2.bias, dil);
   };
   auto by_taps = [&](auto mt) {
