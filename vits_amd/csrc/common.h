@@ -166,7 +166,8 @@ void prof_end(const ProfTicket& t, const char* name, bool gate, const ConvArgs& 
 // LDS-DMA conv on v_mfma_f32_16x16x32_f16 (kernels_gl16.hip): the 7- / 11-tap shapes of the staged-input f16x2 convs.
 // launch_conv's LDS-DMA branch asks conv_gl16_takes after its own checks (staged input, rows % 64, grid size).
 bool conv_gl16_takes(const ConvArgs& a);
-hipError_t launch_conv_gl16(ConvArgs& a, bool wide, bool tall, hipStream_t stream);
+int conv_gl16_tile_width(const ConvArgs& a);          // 256 / 192 / 128 time steps per 128-row block
+hipError_t launch_conv_gl16(ConvArgs& a, int bn, hipStream_t stream);   // bn = 0: 64-row blocks
 
 // ---------------------------------------------------------------------------------------------------------
 // other kernels (kernels_misc.hip)

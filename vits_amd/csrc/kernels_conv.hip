@@ -1767,9 +1767,9 @@ static bool try_launch_gl(ConvArgs& a, hipStream_t stream, hipError_t& err) {
     return e && e[0] ? atoll(e) : -1LL;
   }();
   if (blocks_of(wide || !tall ? 256 : 128) <= (min_blocks >= 0 ? min_blocks : slots / 2)) return false;
-  // 7 and 11 taps: the 16 x 16 x 32 build
+  // 7 and 11 taps: the 16 x 16 x 32 build, with the tile width that needs the fewest block rounds
   if (conv_gl16_takes(a)) {
-    err = launch_conv_gl16(a, wide, tall, stream);
+    err = launch_conv_gl16(a, tall ? conv_gl16_tile_width(a) : 0, stream);
     return true;
   }
   // look-ahead D steps; the activation tile goes out A chunks ahead with A * K >= D

@@ -190,8 +190,8 @@ __device__ __forceinline__ void epilogue16(const ConvArgs& a, f32x4 (&acc)[4][NT
 // S: ring slots of one flat step's weights each (even; the look-ahead is (S - 2) / 2 pair steps).
 template <int WN, int WGM, int WGN, int K, int S>
 __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
-  constexpr int SUBN = WN == 4 ? 1 : 2;          // 16-column tiles per sub-step (the 64 x 128 wave tile has 128 accumulator
-                                                 // registers: two sets of four activation fragments would spill)
+  constexpr int SUBN = WN == 2 ? 2 : 1;          // 16-column tiles per sub-step (the wider wave tiles have 96 / 128
+                                                 // accumulator registers: two sets of four activation fragments would spill)
   constexpr int NSUB = 2 * WN / SUBN;            // sub-steps per pair step
   constexpr int BM = 64 * WGM, BN = 32 * WN * WGN;
   constexpr int NCOLS = BN + MAX_HALO;           // tile columns: a multiple of 64, halo included
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
   constexpr int LA = (S - 2) / 2;                // pair steps between a request and its use
   constexpr int TRIP = 2 * K;                    // pair steps per loop trip (four chunks)
   constexpr int NT = 2 * WN;                     // 16-column accumulator tiles per wave
-  static_assert(WN == 2 || WN == 4, "wave tile 64 x 64 or 64 x 128");
+  static_assert(WN >= 2 && WN <= 4 && NSUB % 2 == 0, "wave tile 64 x 64, 64 x 96 or 64 x 128; sub-steps alternate two register sets");
   static_assert(WGM * WGN == 4, "four waves per block");
   static_assert(K % 2 == 1 && K >= 5, "odd tap counts of at least five (an activation tile goes out (K - 1) / 2 pair steps ahead)");
   static_assert(S % 2 == 0 && S >= 4 && LA < (K - 1) / 2, "weights are requested after the activation tile they go with");
@@ -463,14 +463,38 @@ hipError_t launch_cfg(ConvArgs& a, hipStream_t stream) {
 }  // namespace
 
 // The 7- and 11-tap shapes of the LDS-DMA conv (the launcher in kernels_conv.hip has already checked everything the
-// two kernels share: staged input, rows % 64, grid size).  wide: 128 x 256 block tiles, tall: 128 rows per block.
+// two kernels share: staged input, rows % 64, grid size).
 bool conv_gl16_takes(const ConvArgs& a) {
   return gl16_enabled() && (a.K == 7 || a.K == 11) && a.Cin % 64 == 0;
 }
 
-hipError_t launch_conv_gl16(ConvArgs& a, bool wide, bool tall, hipStream_t stream) {
-  if (wide) return a.K == 7 ? launch_cfg<4, 2, 2, 7, 4>(a, stream) : launch_cfg<4, 2, 2, 11, 4>(a, stream);
-  if (tall) return a.K == 7 ? launch_cfg<2, 2, 2, 7, 6>(a, stream) : launch_cfg<2, 2, 2, 11, 6>(a, stream);
+// Block tile width for a 128-row-block launch: 256, 192 or 128 time steps.  A launch is a number of rounds of the chip's
+// 2 * CUs block slots, and a round costs a block's time whether the round is full or not: 16 rows of 16 512 steps are
+// 1040 tiles of 256 on 1024 slots -- a third round for 16 blocks -- but 1376 tiles of 192, three rounds of blocks three
+// quarters the size.  Cost = rounds * (width + 48): the 48 stands for a block's fixed part (prologue, epilogue, the
+// weight stream, which does not shrink with the tile).  VITS_CONV_GL16_BN=<width> fixes the choice (A/B measurements).
+int conv_gl16_tile_width(const ConvArgs& a) {
+  static const int fixed = [] {
+    const char* e = getenv("VITS_CONV_GL16_BN");
+    return e && e[0] ? atoi(e) : 0;
+  }();
+  if (fixed == 128 || fixed == 192 || fixed == 256) return fixed;
+  const long long slots = 2LL * device_cu_count();
+  int best = 0;
+  long long best_cost = 0;
+  for (int bn : {256, 192, 128}) {
+    const long long blocks = (long long)((a.L + bn - 1) / bn) * (a.M / 128) * a.B;
+    const long long cost = ((blocks + slots - 1) / slots) * (bn + 48);
+    if (!best || cost < best_cost) { best = bn; best_cost = cost; }
+  }
+  return best;
+}
+
+// bn: block tile width for 128-row blocks (M % 128 == 0), 0 for 64-row blocks (64 x 256 tiles)
+hipError_t launch_conv_gl16(ConvArgs& a, int bn, hipStream_t stream) {
+  if (bn == 256) return a.K == 7 ? launch_cfg<4, 2, 2, 7, 4>(a, stream) : launch_cfg<4, 2, 2, 11, 4>(a, stream);
+  if (bn == 192) return a.K == 7 ? launch_cfg<3, 2, 2, 7, 4>(a, stream) : launch_cfg<3, 2, 2, 11, 4>(a, stream);
+  if (bn == 128) return a.K == 7 ? launch_cfg<2, 2, 2, 7, 6>(a, stream) : launch_cfg<2, 2, 2, 11, 6>(a, stream);
   return a.K == 7 ? launch_cfg<2, 1, 4, 7, 6>(a, stream) : launch_cfg<2, 1, 4, 11, 6>(a, stream);
 }
 
