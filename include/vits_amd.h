@@ -204,6 +204,11 @@ int vits_op_conv1d(const void* packed_w, const float* bias_rows, int cin, int ro
 int vits_op_resblock_pair(const void* packed_w1, const float* bias1, const void* packed_w2, const float* bias2,
                           int channels, int taps, int dilation, const float* x, float* out, int B, int L,
                           int accumulate, float slope, void* stream);
+/* The same pair with bf16-packed weights and bf16 operands (precision 2; precision 3 is vits_op_resblock_pair): what
+ * the plain-bf16 generator mode launches for its 32- and 64-channel stages. */
+int vits_op_resblock_pair_prec(const void* packed_w1, const float* bias1, const void* packed_w2, const float* bias2,
+                               int channels, int taps, int dilation, int precision, const float* x, float* out, int B,
+                               int L, int accumulate, float slope, void* stream);
 int vits_op_layer_norm(const float* x, float* y, const float* gamma, const float* beta, const int* lengths, int B, int C,
                        int L, int mask_out, void* stream);
 int vits_op_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out, int B,

@@ -329,6 +329,41 @@ def test_resblock_pair_fused(N, C, k, dil, L, B, acc):
     assert (out.cpu() - y).abs().max() < 5e-5
 
 
+@pytest.mark.parametrize("C,k,dil,L,B,acc", [(32, 3, 1, 1000, 2, False), (32, 7, 3, 3000, 2, True),
+                                             (32, 11, 5, 2500, 3, False), (32, 11, 1, 224, 1, True),
+                                             (64, 3, 1, 1000, 2, True), (64, 7, 5, 97, 3, False), (64, 11, 3, 500, 2, True)])
+def test_resblock_pair_fused_bf16(N, C, k, dil, L, B, acc):
+    """The fused pair in the plain-bf16 arithmetic (what precision="bf16" launches for the 32- and 64-channel stages)
+    against the two separate bf16 convs, with and without the staged tensor between them: the same roundings, the same
+    order of additions, so the same bytes; and against fp32 math on bf16-rounded operands."""
+    from vits_amd import weights
+    p = PREC["bf16"]
+    g = torch.Generator().manual_seed(k * 100 + dil + L + 7)
+    w1 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    w2 = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    b1, b2 = dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g))
+    x = dev(torch.randn(B, C, L, generator=g))
+    init = dev(torch.randn(B, C, L, generator=g))
+    pk1, pk2 = dev(weights.pack_rows(w1, p)), dev(weights.pack_rows(w2, p))
+    stream = torch.cuda.current_stream().cuda_stream
+    t = torch.empty(B, C, L, device="cuda")
+    N.check(N.lib.vits_op_conv1d(pk1.data_ptr(), b1.data_ptr(), C, C, k, dil, 0, p, x.data_ptr(), B, L, 0, 0, 0, 0,
+                                 t.data_ptr(), N.F_IN_LRELU, 1.0, 0.1, stream), "conv1")
+    ref = init.clone()
+    N.check(N.lib.vits_op_conv1d(pk2.data_ptr(), b2.data_ptr(), C, C, k, 1, 0, p, t.data_ptr(), B, L, 0, 0, 0,
+                                 x.data_ptr(), ref.data_ptr(), N.F_IN_LRELU | N.F_RES | (N.F_ACCUM if acc else 0), 1.0,
+                                 0.1, stream), "conv2")
+    out = init.clone()
+    N.check(N.lib.vits_op_resblock_pair_prec(pk1.data_ptr(), b1.data_ptr(), pk2.data_ptr(), b2.data_ptr(), C, k, dil, p,
+                                             x.data_ptr(), out.data_ptr(), B, L, 1 if acc else 0, 0.1, stream), "pair")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    xc = x.cpu()
+    y = F.conv1d(rq(F.leaky_relu(xc, 0.1), p), rq(w1, p), b1.cpu(), padding=(k - 1) // 2 * dil, dilation=dil)
+    y = F.conv1d(rq(F.leaky_relu(y, 0.1), p), rq(w2, p), b2.cpu(), padding=(k - 1) // 2) + xc + (init.cpu() if acc else 0)
+    assert (out.cpu() - y).abs().max() < 2e-2          # a bf16 rounding of the intermediate can flip on its last bit
+
+
 @pytest.mark.parametrize("C,k,dil", [(32, 13, 1), (32, 4, 1), (32, 11, 6), (96, 3, 1), (32, 1, 1)])
 def test_resblock_pair_refuses_unsupported_shapes(N, C, k, dil):
     """Tap counts without an instantiation (odd, 3..11), a first-conv halo over 25 steps and other channel counts

@@ -2337,7 +2337,9 @@ constexpr int PAIR_YOFF = 16;
 // ~560; fetched only one tap ahead of its MFMAs (192 cycles a tap) the matrix pipe sat idle most of the time.
 constexpr int PAIR_AHEAD = 3;
 
-template <int MT, int K>
+// NP: operand planes.  2: PREC_F16X2 (fp16 h / l, three products a tap).  1: PREC_BF16 (operands rounded to bf16, one
+// product a tap; the same staging, the same order of additions as conv_bf16_kernel with a staged intermediate).
+template <int MT, int K, int NP = 2>
 __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a, const uint4* __restrict__ w1,
                                                                const float* __restrict__ b1,
                                                                const uint4* __restrict__ w2,
@@ -2353,8 +2355,8 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
   const int b = blockIdx.z, t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
   const int h1 = (K - 1) / 2 * dil, h2 = (K - 1) / 2;
   const int ncols = W1 + 2 * h1;                            // x tile: times t0 - 16 - h1 ... , one column per time step
-  uint4* xq = lds;                                          // [2 planes][2 halves][ncols]: one 16-channel chunk at a time
-  uint4* yq = lds + 4 * ncols;                              // [NCH chunks][2 planes][2 halves][W1] (+ slack)
+  uint4* xq = lds;                                          // [NP planes][2 halves][ncols]: one 16-channel chunk at a time
+  uint4* yq = lds + 2 * NP * ncols;                         // [NCH chunks][NP planes][2 halves][W1] (+ slack)
   const float* xb = a.x + (long long)b * a.x_bs;
   const int tx0 = t0 - PAIR_YOFF - h1;
 
@@ -2394,20 +2396,29 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
       for (int u = 0; u < 2; ++u) {
         float e = v16[2 * c2 + u];
         e = fmaxf(e, e * a.slope);
-        amax = fmaxf(amax, fabsf(e));
-        e = fminf(fmaxf(e, -65504.f), 65504.f);
+        if constexpr (NP == 2) {
+          amax = fmaxf(amax, fabsf(e));
+          e = fminf(fmaxf(e, -65504.f), 65504.f);
+        }
         v[u] = ok ? e : 0.f;
       }
-      const f16x2 h = __builtin_convertvector(v, f16x2);
-      const f16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), f16x2);
-      ph[c2] = __builtin_bit_cast(unsigned, h);
-      pl[c2] = __builtin_bit_cast(unsigned, l);
+      if constexpr (NP == 2) {
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        const f16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), f16x2);
+        ph[c2] = __builtin_bit_cast(unsigned, h);
+        pl[c2] = __builtin_bit_cast(unsigned, l);
+      } else {
+        ph[c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+      }
     }
-    if (ok) report_f16_range(a.range_flag, amax);
+    if constexpr (NP == 2) {
+      if (ok) report_f16_range(a.range_flag, amax);
+    }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       xq[(0 * 2 + hf) * ncols + col] = make_uint4(ph[4 * hf], ph[4 * hf + 1], ph[4 * hf + 2], ph[4 * hf + 3]);
-      xq[(1 * 2 + hf) * ncols + col] = make_uint4(pl[4 * hf], pl[4 * hf + 1], pl[4 * hf + 2], pl[4 * hf + 3]);
+      if constexpr (NP == 2)
+        xq[(1 * 2 + hf) * ncols + col] = make_uint4(pl[4 * hf], pl[4 * hf + 1], pl[4 * hf + 2], pl[4 * hf + 3]);
     }
   };
   auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
@@ -2427,18 +2438,23 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
   };
   auto mma = [&](const uint4& af, const uint4 (&bf)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, bf[j]),
-                                                      acc[j], 0, 0, 0);
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (NP == 2)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, bf[j]),
+                                                        acc[j], 0, 0, 0);
+      else
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf[j]),
+                                                         acc[j], 0, 0, 0);
+    }
   };
 
   // weight ring: tap g of the virtual sequence [first conv's NT taps, second conv's NT taps] lives in slot g % D
-  uint4 Aq[D][2];
+  uint4 Aq[D][NP];
   auto fetch_a = [&](int g) __attribute__((always_inline)) {
     if (g < 2 * NT) {
-      const uint4* wk = (g < NT ? w1 : w2) + ((long long)(g < NT ? g : g - NT) * MT + wm) * 128 + lane;
-      Aq[g % D][0] = wk[0];
-      Aq[g % D][1] = wk[64];
+      const uint4* wk = (g < NT ? w1 : w2) + ((long long)(g < NT ? g : g - NT) * MT + wm) * (64 * NP) + lane;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) Aq[g % D][p] = wk[64 * p];
     }
   };
 #pragma unroll
@@ -2452,17 +2468,20 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int g = chunk * K + k;
-        const uint4 Ah = Aq[g % D][0], Al = Aq[g % D][1];
         const int off = colbase + k * dil;
         uint4 Bh[2], Bl[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           Bh[j] = xq[off + j * 32];
-          Bl[j] = xq[2 * ncols + off + j * 32];
+          if constexpr (NP == 2) Bl[j] = xq[2 * ncols + off + j * 32];
         }
-        mma(Ah, Bl);                                       // h * l
-        mma(Ah, Bh);                                       // h * h
-        mma(Al, Bh);                                       // l * h
+        if constexpr (NP == 2) {
+          mma(Aq[g % D][0], Bl);                           // h * l
+          mma(Aq[g % D][0], Bh);                           // h * h
+          mma(Aq[g % D][NP - 1], Bh);                      // l * h
+        } else {
+          mma(Aq[g % D][0], Bh);
+        }
         fetch_a(g + D);
       }
     };
@@ -2495,21 +2514,27 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
           for (int q = 0; q < 2; ++q) {
             float v = acc[j][4 * g + 2 * u + q] + bz[4 * g + 2 * u + q];
             v = fmaxf(v, v * a.slope);
-            ymax = fmaxf(ymax, fabsf(v));
-            v = fminf(fmaxf(v, -65504.f), 65504.f);
+            if constexpr (NP == 2) {
+              ymax = fmaxf(ymax, fabsf(v));
+              v = fminf(fmaxf(v, -65504.f), 65504.f);
+            }
             e[q] = inside ? v : 0.f;
           }
-          const f16x2 h = __builtin_convertvector(e, f16x2);
-          const f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, f32x2), f16x2);
-          (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, h);
-          (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, l);
+          if constexpr (NP == 2) {
+            const f16x2 h = __builtin_convertvector(e, f16x2);
+            const f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, f32x2), f16x2);
+            (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, h);
+            (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, l);
+          } else {
+            (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2));
+          }
         }
         const int chunk2 = 2 * wm + (g >> 1), half = g & 1;
-        y2[(((chunk2 * 2 + 0) * 2 + half) * W1 + c) * 2 + par] = oh;
-        y2[(((chunk2 * 2 + 1) * 2 + half) * W1 + c) * 2 + par] = ol;
+        y2[(((chunk2 * NP + 0) * 2 + half) * W1 + c) * 2 + par] = oh;
+        if constexpr (NP == 2) y2[(((chunk2 * NP + 1) * 2 + half) * W1 + c) * 2 + par] = ol;
       }
     }
-    report_f16_range(a.range_flag, ymax);
+    if constexpr (NP == 2) report_f16_range(a.range_flag, ymax);
   }
   __syncthreads();
   // ---- second conv on the inner BN steps ----
@@ -2521,17 +2546,20 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int g = NT + chunk * K + k;
-        const uint4 Ah = Aq[g % D][0], Al = Aq[g % D][1];
-        const int off = (chunk * 4) * W1 + obase + k;
+        const int off = (chunk * 2 * NP) * W1 + obase + k;
         uint4 Bh[2], Bl[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           Bh[j] = yq[off + j * 32];
-          Bl[j] = yq[2 * W1 + off + j * 32];
+          if constexpr (NP == 2) Bl[j] = yq[2 * W1 + off + j * 32];
         }
-        mma(Ah, Bl);
-        mma(Ah, Bh);
-        mma(Al, Bh);
+        if constexpr (NP == 2) {
+          mma(Aq[g % D][0], Bl);
+          mma(Aq[g % D][0], Bh);
+          mma(Aq[g % D][NP - 1], Bh);
+        } else {
+          mma(Aq[g % D][0], Bh);
+        }
         fetch_a(g + D);
       }
   }
@@ -2588,11 +2616,17 @@ static bool pair64_taps(int K) {
 }
 
 bool pair_profitable(const ConvDesc& c1, const ConvDesc& c2) {
+  // plain bf16: one product a tap, so the recomputed halo of the 96-step tiles costs little and every layer is bound
+  // by its traffic, which the fused pair halves: every 32- and 64-channel pair
+  if (pair_fusable(c1, c2) && c1.prec == PREC_BF16) {
+    static const std::string v = getenv("VITS_PAIR64_BF16") ? getenv("VITS_PAIR64_BF16") : "3,5,7,9,11";
+    return c1.M == 32 || ("," + v + ",").find("," + std::to_string(c1.K) + ",") != std::string::npos;
+  }
   return pair_fusable(c1, c2) && (c1.M == 32 || pair64_taps(c1.K));
 }
 
 bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2) {
-  const bool shape = c1.prec == PREC_F16X2 && c2.prec == PREC_F16X2 && c1.mode == MODE_PLAIN && c2.mode == MODE_PLAIN &&
+  const bool shape = (c1.prec == PREC_F16X2 || c1.prec == PREC_BF16) && c2.prec == c1.prec && c1.mode == MODE_PLAIN && c2.mode == MODE_PLAIN &&
                      c1.M == c1.Cin && c2.M == c1.M && c2.Cin == c1.M && c1.K == c2.K && (c1.K & 1) && c2.tstep[0] == 1 &&
                      (c1.K - 1) / 2 * c1.tstep[0] <= 25 && (c2.K - 1) / 2 <= PAIR_YOFF;
   return shape && (c1.M == 32 || c1.M == 64) && c1.K >= 3 && c1.K <= 11;
@@ -2603,21 +2637,29 @@ hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const Pa
   const int K = c1.K, dil = c1.tstep[0], MT = c1.M / 32;
   const int W1 = 64 * (4 / MT), BN = W1 - 32, nch = 2 * MT;
   const int ncols = W1 + 2 * ((K - 1) / 2 * dil);
-  const size_t lds = ((size_t)4 * ncols + (size_t)nch * 4 * W1 + 64) * sizeof(uint4);   // + slack for the invalid n-tile
+  const int NP = c1.prec == PREC_BF16 ? 1 : 2;
+  // operand tiles (+ slack for the invalid n-tile); the result tile ([32 * MT rows][BN + 8] fp32) reuses the Y tile's
+  // space and, with one plane, needs more than that
+  size_t lds = ((size_t)2 * NP * ncols + (size_t)nch * 2 * NP * W1 + 64) * sizeof(uint4);
+  lds = std::max(lds, (size_t)2 * NP * ncols * sizeof(uint4) + (size_t)32 * MT * (BN + 8) * sizeof(float));
   dim3 grid((a.L + BN - 1) / BN, 1, a.B);
   ConvArgs ta;
   memset(&ta, 0, sizeof ta);
   ta.M = c1.M; ta.Cin = c1.M; ta.K = 2 * K; ta.L = a.L; ta.B = a.B;      // timing row: both convs' FLOPs
   ta.flags = a.accumulate ? F_ACCUM : 0;       // bytes: x once (the residual is the same tensor), the result, the sum
   char name[64];
-  snprintf(name, sizeof name, "resblock_pair_kernel<%d,%d>", MT, K);
+  snprintf(name, sizeof name, NP == 1 ? "resblock_pair_bf16_kernel<%d,%d>" : "resblock_pair_kernel<%d,%d>", MT, K);
   const uint4* w1 = reinterpret_cast<const uint4*>(c1.w);
   const uint4* w2 = reinterpret_cast<const uint4*>(c2.w);
   PairArgs pa = a;
   pa.xcd_map = xcd_map_enabled();
   auto go = [&](auto mt, auto kk) {
-    hipLaunchKernelGGL((resblock_pair_kernel<decltype(mt)::value, decltype(kk)::value>), grid, dim3(256), lds, stream, pa,
-                       w1, c1.bias, w2, c2.bias, dil);
+    if (NP == 1)
+      hipLaunchKernelGGL((resblock_pair_kernel<decltype(mt)::value, decltype(kk)::value, 1>), grid, dim3(256), lds, stream,
+                         pa, w1, c1.bias, w2, c2.bias, dil);
+    else
+      hipLaunchKernelGGL((resblock_pair_kernel<decltype(mt)::value, decltype(kk)::value, 2>), grid, dim3(256), lds, stream,
+                         pa, w1, c1.bias, w2, c2.bias, dil);
   };
   auto by_taps = [&](auto mt) {
     switch (K) {

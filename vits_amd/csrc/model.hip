@@ -1140,9 +1140,18 @@ int vits_op_conv1d(const void* w, const float* bias, int cin, int rows, int taps
 int vits_op_resblock_pair(const void* w1, const float* b1, const void* w2, const float* b2, int channels, int taps,
                           int dilation, const float* x, float* out, int B, int L, int accumulate, float slope,
                           void* stream) {
+  return vits_op_resblock_pair_prec(w1, b1, w2, b2, channels, taps, dilation, PREC_F16X2, x, out, B, L, accumulate, slope,
+                                    stream);
+}
+
+int vits_op_resblock_pair_prec(const void* w1, const float* b1, const void* w2, const float* b2, int channels, int taps,
+                               int dilation, int precision, const float* x, float* out, int B, int L, int accumulate,
+                               float slope, void* stream) {
+  if (precision != PREC_F16X2 && precision != PREC_BF16)
+    return fail(VITS_ERR_INVALID, "resblock pair: precision must be f16x2 (3) or bf16 (2)");
   ConvDesc c1, c2;
-  TRY(make_desc(c1, w1, b1, channels, channels, taps, dilation, MODE_PLAIN, PREC_F16X2));
-  TRY(make_desc(c2, w2, b2, channels, channels, taps, 1, MODE_PLAIN, PREC_F16X2));
+  TRY(make_desc(c1, w1, b1, channels, channels, taps, dilation, MODE_PLAIN, precision));
+  TRY(make_desc(c2, w2, b2, channels, channels, taps, 1, MODE_PLAIN, precision));
   if (!pair_fusable(c1, c2))
     return fail(VITS_ERR_INVALID, "resblock pair: 32 or 64 channels, 3 / 5 / 7 / 9 / 11 taps, first-conv halo <= 25 required");
   if (x == out) return fail(VITS_ERR_INVALID, "resblock pair: cannot run in place");
