@@ -92,9 +92,10 @@ def pmc_traffic(kernel, workload):
     this benchmark's command (profiles/*_pmc_traffic.json, newest first: the command, the gfx950 FETCH_SIZE correction
     and its check are recorded there); None when no pass covers the kernel or the passes ran on another shape or
     precision."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    import glob
+    for name in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
+            with open(name) as f:
                 table = json.load(f)
             if table["workload"] != workload:
                 continue
