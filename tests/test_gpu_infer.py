@@ -20,8 +20,7 @@ MEL_TOL = 1e-3
 LATENT_TOL = 2e-4      # z / z_p reach |20|; m_p, logs_p, stage tensors are O(1)
 
 
-@pytest.fixture(scope="module")
-def gpu_model(synthetic_sd):
+def _gpu_model(synthetic_sd):
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
     from vits_amd import SynthesizerTrn
     cfg = synthetic.ModelConfig()
@@ -29,6 +28,11 @@ def gpu_model(synthetic_sd):
                          **cfg.kwargs()).eval()
     net.load_state_dict(synthetic_sd)
     return net
+
+
+@pytest.fixture(scope="module")
+def gpu_model(synthetic_sd):
+    return _gpu_model(synthetic_sd)
 
 
 @pytest.mark.parametrize("name", SMALL_CASES)
@@ -351,6 +355,34 @@ def test_infer_c4_corpus_slice(gpu_model, oracle_model):
         assert metrics.max_abs(o1, ref1) <= WAV_TOL
         assert metrics.log_mel_l1(o1[:, 0], ref1[:, 0]) <= MEL_TOL
     assert not gpu_model.range_overflow()
+
+
+def test_corpus_batches_do_not_depend_on_the_rank_count(gpu_model, synthetic_sd):
+    """The sharded corpus path (BASELINE configs[3] on N GPUs): batch composition is fixed before the batches are dealt
+    to ranks, so every batch must come out with the same bytes whichever rank synthesises it, after whichever other
+    batches.  One GPU plays the ranks in turn: N = 1 (one model, every batch in corpus order), then N = 2 and N = 4
+    with a second model instance (its own workspaces, as another process would have) running each rank's share through
+    infer_batches, the path the corpus benchmark uses."""
+    from vits_amd import sharding
+    batches = synthetic.corpus_c4(500)
+    assert len(batches) >= 8 and any(len(set(ts)) > 1 for _, ts in batches)
+
+    def kw_of(i):
+        b = synthetic.make_batch(1000 + i, *batches[i])
+        return dict(phonemes=b.phonemes, phonemes_lengths=b.lengths, sid=b.sid, noise_scale=b.noise_scale,
+                    duration_control=b.durations, noise=b.noise)
+
+    whole = [g[0].clone() for g in gpu_model.infer_batches([kw_of(i) for i in range(len(batches))])]
+    other = _gpu_model(synthetic_sd)
+    for world in (2, 4):
+        seen = []
+        for rank in range(world):
+            mine = sharding.deal_batches(batches, world, rank)
+            seen += mine
+            for i, g in zip(mine, other.infer_batches([kw_of(i) for i in mine])):
+                assert torch.equal(g[0], whole[i]), (world, rank, i)
+        assert sorted(seen) == list(range(len(batches)))
+    assert not gpu_model.range_overflow() and not other.range_overflow()
 
 
 def test_generator_chain_with_unfusable_pair(synthetic_sd):
