@@ -331,7 +331,10 @@ def test_resblock_pair_fused(N, C, k, dil, L, B, acc):
 
 @pytest.mark.parametrize("C,k,dil,L,B,acc", [(32, 3, 1, 1000, 2, False), (32, 7, 3, 3000, 2, True),
                                              (32, 11, 5, 2500, 3, False), (32, 11, 1, 224, 1, True),
-                                             (64, 3, 1, 1000, 2, True), (64, 7, 5, 97, 3, False), (64, 11, 3, 500, 2, True)])
+                                             (64, 3, 1, 1000, 2, True), (64, 7, 5, 97, 3, False), (64, 11, 3, 500, 2, True),
+                                             # 64 channels: 224-step tiles, lengths on and around a tile boundary
+                                             (64, 3, 5, 224, 1, False), (64, 11, 1, 225, 2, False),
+                                             (64, 5, 3, 1345, 2, True), (64, 9, 1, 449, 1, True)])
 def test_resblock_pair_fused_bf16(N, C, k, dil, L, B, acc):
     """The fused pair in the plain-bf16 arithmetic (what precision="bf16" launches for the 32- and 64-channel stages)
     against the two separate bf16 convs, with and without the staged tensor between them: the same roundings, the same

@@ -2339,12 +2339,18 @@ constexpr int PAIR_AHEAD = 3;
 
 // NP: operand planes.  2: PREC_F16X2 (fp16 h / l, three products a tap).  1: PREC_BF16 (operands rounded to bf16, one
 // product a tap; the same staging, the same order of additions as conv_bf16_kernel with a staged intermediate).
-template <int MT, int K, int NP = 2>
-__global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a, const uint4* __restrict__ w1,
+// WR: 32-row tiles per wave.  1: MT waves side by side in rows.  2 (64 channels, one plane): every wave owns all 64 rows
+// of its 64 columns, so an activation fragment read from LDS feeds two MFMAs and a weight fragment two as well --
+// with one product a tap the 32 x 64 wave tile asks LDS and the vector cache for a kilobyte per MFMA, which is all
+// either delivers -- and the tile is 256 steps wide (224 outputs: a seventh of the first conv recomputed, not a third).
+template <int MT, int K, int NP = 2, int WR = 1>
+__global__ __launch_bounds__(256, WR == 2 ? 2 : 3) void resblock_pair_kernel(const PairArgs a, const uint4* __restrict__ w1,
                                                                const float* __restrict__ b1,
                                                                const uint4* __restrict__ w2,
                                                                const float* __restrict__ b2, int dil) {
-  constexpr int WGN = 4 / MT, W1 = 64 * WGN, BN = W1 - 32, NCH = 2 * MT;
+  static_assert(MT % WR == 0, "whole waves in rows");
+  constexpr int WGM = MT / WR, WGN = 4 / WGM, W1 = 64 * WGN, BN = W1 - 32, NCH = 2 * MT;
+  constexpr int CPT = NCH * W1 / 256;                       // 16-channel chunks of its column a thread loads and keeps
   constexpr int NT = NCH * K, D = PAIR_AHEAD;               // taps per conv; depth of the weight ring
   constexpr int OP = BN + 8;                                // row pitch of the result tile in LDS (floats)
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
@@ -2363,8 +2369,9 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
   // The whole x tile is requested at once, before anything else: one memory round trip per block instead of one per
   // chunk plus one for the residual.
   //   * thread (c, cp) = (tid % W1, tid / W1) owns tile column c + h1 (time t0 - 16 + c: the W1 columns under the first
-  //     conv's outputs, which include every column the block writes) for the chunks 2 cp, 2 cp + 1: 32 raw values that
-  //     stay in registers to the end -- they are the residual of the block's own outputs, so x is never read twice;
+  //     conv's outputs, which include every column the block writes) for the chunks CPT cp .. CPT cp + CPT - 1: 16 CPT
+  //     raw values that stay in registers to the end -- they are the residual of the block's own outputs, so x is
+  //     never read twice;
   //   * the 2 * h1 halo columns on either side: thread tid < 2 * h1 * NCH takes (column, chunk) item tid.
   const int oc = tid % W1, ocp = tid / W1;
   const int ot = t0 - PAIR_YOFF + oc;                       // this thread's own column: its time step
@@ -2374,11 +2381,11 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
   const int hcol = hidx < h1 ? hidx : W1 + hidx;            // tile column: left halo [0, h1), right halo [W1 + h1, ncols)
   const int ht = tx0 + hcol;
   const bool h_has = tid < nh, h_ok = h_has && ht >= 0 && ht < a.L;
-  float st[2][16], sb[16];
+  float st[CPT][16], sb[16];
   {
-    const float* xo = xb + (long long)(ocp * 32) * a.x_cs + (o_ok ? ot : 0);
+    const float* xo = xb + (long long)(ocp * 16 * CPT) * a.x_cs + (o_ok ? ot : 0);
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < CPT; ++u)
 #pragma unroll
       for (int ci = 0; ci < 16; ++ci) st[u][ci] = xo[(long long)(u * 16 + ci) * a.x_cs];
     const float* xh = xb + (long long)(hch * 16) * a.x_cs + (h_ok ? ht : 0);
@@ -2422,39 +2429,43 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
     }
   };
   auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
-    if ((chunk >> 1) == ocp) {
-      if (chunk & 1) put(st[1], oc + h1, o_ok);
-      else put(st[0], oc + h1, o_ok);
-    }
+    if (chunk / CPT == ocp) put(st[chunk % CPT], oc + h1, o_ok);       // chunk is a compile-time constant
     if (h_has && hch == chunk) put(sb, hcol, h_ok);
   };
 
-  f32x16 acc[2];
+  f32x16 acc[WR][2];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < WR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
-  auto mma = [&](const uint4& af, const uint4 (&bf)[2]) __attribute__((always_inline)) {
+  // one product of a tap: plane pa of the weights (every row tile of the wave) x the given activation fragments
+  auto mma = [&](const uint4 (&af)[WR][NP], int pa, const uint4 (&bf)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if constexpr (NP == 2)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, bf[j]),
-                                                        acc[j], 0, 0, 0);
-      else
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf[j]),
-                                                         acc[j], 0, 0, 0);
-    }
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (NP == 2)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][pa]),
+                                                             __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][pa]),
+                                                              __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+      }
   };
 
   // weight ring: tap g of the virtual sequence [first conv's NT taps, second conv's NT taps] lives in slot g % D
-  uint4 Aq[D][NP];
+  uint4 Aq[D][WR][NP];
   auto fetch_a = [&](int g) __attribute__((always_inline)) {
     if (g < 2 * NT) {
-      const uint4* wk = (g < NT ? w1 : w2) + ((long long)(g < NT ? g : g - NT) * MT + wm) * (64 * NP) + lane;
+      const uint4* wk = (g < NT ? w1 : w2) + ((long long)(g < NT ? g : g - NT) * MT + wm * WR) * (64 * NP) + lane;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) Aq[g % D][p] = wk[64 * p];
+      for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) Aq[g % D][i][p] = wk[64 * (i * NP + p)];
     }
   };
 #pragma unroll
@@ -2476,11 +2487,11 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
           if constexpr (NP == 2) Bl[j] = xq[2 * ncols + off + j * 32];
         }
         if constexpr (NP == 2) {
-          mma(Aq[g % D][0], Bl);                           // h * l
-          mma(Aq[g % D][0], Bh);                           // h * h
-          mma(Aq[g % D][NP - 1], Bh);                      // l * h
+          mma(Aq[g % D], 0, Bl);                           // h * l
+          mma(Aq[g % D], 0, Bh);                           // h * h
+          mma(Aq[g % D], NP - 1, Bh);                      // l * h
         } else {
-          mma(Aq[g % D][0], Bh);
+          mma(Aq[g % D], 0, Bh);
         }
         fetch_a(g + D);
       }
@@ -2496,9 +2507,13 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
   // ---- Y = split(lrelu(c1 + bias)), zero outside the sequence; 8-byte pieces (four channels of a half) ----
   {
     uint2* y2 = reinterpret_cast<uint2*>(yq);
-    float bz[16], ymax = 0.f;
+    float ymax = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bz[r] = b1 ? b1[32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+    for (int i = 0; i < WR; ++i) {
+    const int rt = wm * WR + i;                              // this accumulator's 32-row tile
+    float bz[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bz[r] = b1 ? b1[32 * rt + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = wn * 64 + j * 32 + l31;
@@ -2512,7 +2527,7 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
           f32x2 e;
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            float v = acc[j][4 * g + 2 * u + q] + bz[4 * g + 2 * u + q];
+            float v = acc[i][j][4 * g + 2 * u + q] + bz[4 * g + 2 * u + q];
             v = fmaxf(v, v * a.slope);
             if constexpr (NP == 2) {
               ymax = fmaxf(ymax, fabsf(v));
@@ -2529,10 +2544,11 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
             (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2));
           }
         }
-        const int chunk2 = 2 * wm + (g >> 1), half = g & 1;
+        const int chunk2 = 2 * rt + (g >> 1), half = g & 1;
         y2[(((chunk2 * NP + 0) * 2 + half) * W1 + c) * 2 + par] = oh;
         if constexpr (NP == 2) y2[(((chunk2 * NP + 1) * 2 + half) * W1 + c) * 2 + par] = ol;
       }
+    }
     }
     if constexpr (NP == 2) report_f16_range(a.range_flag, ymax);
   }
@@ -2554,11 +2570,11 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
           if constexpr (NP == 2) Bl[j] = yq[2 * W1 + off + j * 32];
         }
         if constexpr (NP == 2) {
-          mma(Aq[g % D][0], Bl);
-          mma(Aq[g % D][0], Bh);
-          mma(Aq[g % D][NP - 1], Bh);
+          mma(Aq[g % D], 0, Bl);
+          mma(Aq[g % D], 0, Bh);
+          mma(Aq[g % D], NP - 1, Bh);
         } else {
-          mma(Aq[g % D][0], Bh);
+          mma(Aq[g % D], 0, Bh);
         }
         fetch_a(g + D);
       }
@@ -2572,34 +2588,50 @@ __global__ __launch_bounds__(256, 3) void resblock_pair_kernel(const PairArgs a,
     float* ob = a.out + (long long)b * a.out_bs;
     const int o = oc - PAIR_YOFF, t = t0 + o;
     const bool mine = o >= 0 && o < BN && t < a.L;
-    float ov[32];
-    if (a.accumulate) {                                    // requested before the barriers below
+    constexpr int NR = 16 * CPT;                           // rows this thread finishes: those it loaded
+    constexpr bool EARLY = CPT <= 2;                       // room for the accumulated output beside everything else
+    float ov[EARLY ? NR : 16];
+    if (EARLY && a.accumulate) {                           // requested before the barriers below
       const int tc = mine ? t : 0;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) ov[i] = ob[(long long)(32 * ocp + i) * a.out_cs + tc];
+      for (int i = 0; i < (EARLY ? NR : 0); ++i) ov[i] = ob[(long long)(NR * ocp + i) * a.out_cs + tc];
     }
-    float bz[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bz[r] = b2 ? b2[32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
     __syncthreads();                                       // every wave has read its last Y fragment
     float* oq = reinterpret_cast<float*>(yq);              // [32 * MT rows][OP]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = wn * 64 + j * 32 + l31;
-      if (col < BN) {
+    for (int i = 0; i < WR; ++i) {
+      const int rt = wm * WR + i;
+      float bz[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          oq[(32 * wm + 4 * par + (r & 3) + 8 * (r >> 2)) * OP + col] = acc[j][r] + bz[r];
+      for (int r = 0; r < 16; ++r) bz[r] = b2 ? b2[32 * rt + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + l31;
+        if (col < BN) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            oq[(32 * rt + 4 * par + (r & 3) + 8 * (r >> 2)) * OP + col] = acc[i][j][r] + bz[r];
+        }
       }
     }
     __syncthreads();
     if (mine) {
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        float v = oq[(32 * ocp + i) * OP + o];
-        v += st[i >> 4][i & 15];
-        if (a.accumulate) v += ov[i];
-        ob[(long long)(32 * ocp + i) * a.out_cs + t] = v;
+      for (int u = 0; u < CPT; ++u) {
+        if constexpr (!EARLY) {
+          if (a.accumulate) {
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) ov[ci] = ob[(long long)(NR * ocp + 16 * u + ci) * a.out_cs + t];
+          }
+        }
+#pragma unroll
+        for (int ci = 0; ci < 16; ++ci) {
+          const int i = 16 * u + ci;
+          float v = oq[(NR * ocp + i) * OP + o];
+          v += st[u][ci];
+          if (a.accumulate) v += ov[EARLY ? i : ci];
+          ob[(long long)(NR * ocp + i) * a.out_cs + t] = v;
+        }
       }
     }
   }
@@ -2635,9 +2667,16 @@ bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2) {
 hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const PairArgs& a, hipStream_t stream) {
   if (!pair_fusable(c1, c2) || a.B <= 0 || a.L <= 0 || a.B > 65535) return hipErrorInvalidValue;
   const int K = c1.K, dil = c1.tstep[0], MT = c1.M / 32;
-  const int W1 = 64 * (4 / MT), BN = W1 - 32, nch = 2 * MT;
-  const int ncols = W1 + 2 * ((K - 1) / 2 * dil);
   const int NP = c1.prec == PREC_BF16 ? 1 : 2;
+  // 64 channels in one plane: every wave takes both row tiles (a 256-step tile, two blocks to a CU).  Measured at
+  // 64 x 10 s per launch with the chains one after the other, against 96-step tiles at three blocks to a CU: k = 3 1.96
+  // against 2.17 ms, k = 7 3.20 / 3.34, k = 11 4.57 / 4.34; with the chains side by side, as the generator runs them,
+  // the whole step is shortest with the wide tile at every tap count (VITS_PAIR_BF16_TALL=<taps>: the largest tap
+  // count that takes it; 0 = never; measured 0 / 7 / 11: 6245 / 6266 / 6405 audio-s/s).
+  static const int tall_taps = getenv("VITS_PAIR_BF16_TALL") ? atoi(getenv("VITS_PAIR_BF16_TALL")) : 11;
+  const int WR = (NP == 1 && MT == 2 && K <= tall_taps) ? 2 : 1;
+  const int W1 = 64 * (4 / (MT / WR)), BN = W1 - 32, nch = 2 * MT;
+  const int ncols = W1 + 2 * ((K - 1) / 2 * dil);
   // operand tiles (+ slack for the invalid n-tile); the result tile ([32 * MT rows][BN + 8] fp32) reuses the Y tile's
   // space and, with one plane, needs more than that
   size_t lds = ((size_t)2 * NP * ncols + (size_t)nch * 2 * NP * W1 + 64) * sizeof(uint4);
@@ -2654,7 +2693,11 @@ hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const Pa
   PairArgs pa = a;
   pa.xcd_map = xcd_map_enabled();
   auto go = [&](auto mt, auto kk) {
-    if (NP == 1)
+    if (NP == 1 && WR == 2) {
+      if constexpr (decltype(mt)::value == 2)
+        hipLaunchKernelGGL((resblock_pair_kernel<2, decltype(kk)::value, 1, 2>), grid, dim3(256), lds, stream,
+                           pa, w1, c1.bias, w2, c2.bias, dil);
+    } else if (NP == 1)
       hipLaunchKernelGGL((resblock_pair_kernel<decltype(mt)::value, decltype(kk)::value, 1>), grid, dim3(256), lds, stream,
                          pa, w1, c1.bias, w2, c2.bias, dil);
     else
