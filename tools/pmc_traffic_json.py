@@ -24,8 +24,9 @@ def per_kernel(path, counter):
             # "true|false, ring")
             name = re.sub(r",true,(\d+)>", lambda m: ",staged>" if m.group(1) == "0" else f",staged,{m.group(1)}>", name)
             # the fused pair's third template argument is its operand-plane count: 2 = f16x2, 1 = plain bf16
-            name = re.sub(r"resblock_pair_kernel<(\d+),(\d+),2>", r"resblock_pair_kernel<\1,\2>", name)
-            name = re.sub(r"resblock_pair_kernel<(\d+),(\d+),1>", r"resblock_pair_bf16_kernel<\1,\2>", name)
+            # (and its fourth the row tiles per wave, which the timing rows leave out)
+            name = re.sub(r"resblock_pair_kernel<(\d+),(\d+),2(,\d+)?>", r"resblock_pair_kernel<\1,\2>", name)
+            name = re.sub(r"resblock_pair_kernel<(\d+),(\d+),1(,\d+)?>", r"resblock_pair_bf16_kernel<\1,\2>", name)
             name = name.replace(",false,0>", ">").replace(",true>", ",staged>").replace(",false>", ">")
             acc[name].append(float(r["Counter_Value"]) * 1024.0)
     return acc
