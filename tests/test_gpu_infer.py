@@ -245,6 +245,16 @@ def test_infer_batches_equals_infer(gpu_model):
         for g, r in zip(got, ref):
             assert torch.equal(g[0], r[0]) and torch.equal(g[1], r[1]) and torch.equal(g[2][0], r[2][0])
             assert torch.equal(g[4], r[4])
+    # from a stream of the caller's own (the generator then keeps to one stream: the process's hardware queues are
+    # counted), with the caller copying every batch to the host while the next one is in flight: the same bytes
+    own = torch.cuda.Stream()
+    with torch.cuda.stream(own):
+        torch.manual_seed(77)
+        got = [tuple(t.to("cpu", non_blocking=True) for t in (g[0], g[1], g[2][0], g[4]))
+               for g in gpu_model.infer_batches(kws)]
+        own.synchronize()
+    for g, r in zip(got, ref):
+        assert all(torch.equal(a, b.cpu()) for a, b in zip(g, (r[0], r[1], r[2][0], r[4])))
     assert list(gpu_model.infer_batches([])) == []
     with pytest.raises(TypeError):
         list(gpu_model.infer_batches([dict(kws[0], bogus=1)]))

@@ -295,7 +295,12 @@ class SynthesizerTrn:
                 caller = torch.cuda.current_stream(dev)
                 if self._last_use is not None and self._last_use[0] != caller:
                     caller.wait_event(self._last_use[1])
-                N.check(lib.vits_model_set_generator_streams(h, int(os.environ.get("VITS_BATCHES_GEN_STREAMS", "2"))),
+                # Hardware queues: one per stream in use, the process's default stream included (normal-priority streams
+                # share four, a high-priority stream has one of its own), and four are what the device schedules at
+                # once.  Called on the default stream that is default + front end + generator + one side stream; a
+                # caller on a stream of its own already holds the fourth, so the generator then stays on one stream.
+                gen_streams = 2 if caller == torch.cuda.default_stream(dev) else 1
+                N.check(lib.vits_model_set_generator_streams(h, int(os.environ.get("VITS_BATCHES_GEN_STREAMS", gen_streams))),
                         "set_generator_streams")
                 # Every host tensor is uploaded before the side streams start, and the loop below issues no blocking
                 # host-to-device copy of its own.
