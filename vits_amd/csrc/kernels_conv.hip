@@ -387,6 +387,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
       }
     }
   } else {  // MODE_UP2: m-tile = 32 channels of one phase
+    if constexpr (WM == 2) {
+      // the wave holds both phases of its 32 channels (m-tiles 2 cb, 2 cb + 1): one 8-byte store per output pair, so a
+      // row is written in whole runs instead of every other float by each of two instructions
+      if (mt_ok[0] && mt_ok[1] && (mt[0] & 1) == 0 && mt[1] == mt[0] + 1) {
+        const int cb = mt[0] >> 1;
+        float bz0[16], bz1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          bz0[r] = a.bias ? a.bias[mt[0] * 32 + (r & 3) + 8 * (r >> 2) + 4 * par] : 0.f;
+          bz1[r] = a.bias ? a.bias[mt[1] * 32 + (r & 3) + 8 * (r >> 2) + 4 * par] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int t = t0 + (wn * WN + j) * 32 + l31;
+          if (t >= a.L) continue;
+          const unsigned lo_out = (unsigned)(4 * par * a.out_cs + 2 * t);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float2 v;
+            v.x = acc[0][j][r] + bz0[r];
+            v.y = acc[1][j][r] + bz1[r];
+            *reinterpret_cast<float2*>(out_b + (long long)(cb * 32 + (r & 3) + 8 * (r >> 2)) * a.out_cs + lo_out) = v;
+          }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       if (!mt_ok[i]) continue;
