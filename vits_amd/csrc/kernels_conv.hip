@@ -2332,10 +2332,15 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
       return launch_cfg<2, 2, 1, 4, MODE_GATE>(a, p, stream);
     case MODE_UP8:
       if (M % 64 != 0) return hipErrorInvalidValue;
+      // taller block tiles: one staged input tile feeds 256 rows (eight phases of 32 channels) instead of 64 or 128.
+      // At 16 x 3 s: 512 -> 256 channels 142 -> 98 us, 256 -> 128 channels 215 -> 164 us; batch-1 latency unchanged.
+      if (M % 256 == 0) return launch_cfg<2, 2, 4, 1, MODE_UP8>(a, p, stream);
       if (L <= 1024) return launch_cfg<2, 1, 2, 2, MODE_UP8>(a, p, stream);
       return launch_cfg<2, 2, 1, 4, MODE_UP8>(a, p, stream);
     case MODE_UP4:
       if (M % 64 != 0) return hipErrorInvalidValue;
+      // 128 rows x 64 steps: one staged input tile feeds twice the rows (155 -> 140 us for 128 -> 64 channels at 16 x 3 s)
+      if (M % 128 == 0) return launch_cfg<2, 2, 2, 2, MODE_UP4>(a, p, stream);
       return launch_cfg<2, 2, 1, 4, MODE_UP4>(a, p, stream);
     case MODE_UP2:
       if (M % 64 != 0) return hipErrorInvalidValue;
