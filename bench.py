@@ -108,7 +108,7 @@ def pmc_traffic(kernel, workload):
 def kernel_peak_tflops(name):
     if name.startswith("conv_mfma_kernel"):
         return PEAK_FP32_MFMA_TFLOPS
-    if name.startswith(("conv_bf16_kernel", "resblock_pair_bf16_kernel")):
+    if name.startswith(("conv_bf16_kernel", "conv_glb_bf16_kernel", "resblock_pair_bf16_kernel")):
         return PEAK_BF16_MFMA_TFLOPS
     if name.startswith(("conv_f16x2_kernel", "conv_gl_", "conv_gl16_", "resblock_pair_kernel")):
         return PEAK_F16X2_TFLOPS

@@ -289,6 +289,68 @@ def test_conv_lds_dma_matches_register_kernel(N, C, k, dil, L, kind):
         assert (whole[:2].cpu() - ref).abs().max() < 5e-5
 
 
+@pytest.mark.parametrize("C,k,dil,L,kind", [(128, 11, 5, 16512, "res"), (128, 3, 1, 16400, "res_acc"),
+                                            (256, 7, 3, 2064, "res"), (256, 11, 1, 2000, "plain"),
+                                            (128, 7, 9, 4100, "staged_out"), (256, 3, 5, 8193, "res")])
+def test_conv_bf16_lds_dma_matches_register_kernel(N, C, k, dil, L, kind):
+    """Staged-input plain-bf16 convs with rows in 128s whose grid fills the chip run on the one-plane LDS-DMA kernel
+    (128 x 256 and 128 x 128 block tiles); a single batch row is a small grid and stays with the register-staging
+    kernel.  A batch of 16 against its rows one at a time, at both sequence ends and across tile borders, for the
+    epilogues the generator uses.  The same bf16 products, summed tap by tap over a pair of 16-channel chunks instead
+    of chunk by chunk: equal to fp32 summation order (1e-5 absolute on sums of magnitude 1..5; a staged bf16 result may
+    differ by one rounding step where a sum sits on a rounding boundary)."""
+    from vits_amd import weights
+    p = PREC["bf16"]
+    g = torch.Generator().manual_seed(C * 31 + k * 7 + L)
+    B = 16
+    w0 = torch.randn(C, C, 3, generator=g) / math.sqrt(C * 3)
+    w = torch.randn(C, C, k, generator=g) / math.sqrt(C * k)
+    pk0, pk = dev(weights.pack_rows(w0, p)), dev(weights.pack_rows(w, p))
+    b0, b = dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g))
+    x = dev(torch.randn(B, C, L, generator=g))
+    init = dev(torch.randn(B, C, L, generator=g))
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = N.F_IN_STAGED | {"res": N.F_RES, "res_acc": N.F_RES | N.F_ACCUM, "staged_out": N.F_OUT_STAGED, "plain": 0}[kind]
+
+    def run(xr, out):
+        n = xr.shape[0]
+        staged = torch.empty(n, C, L, device="cuda")
+        N.check(N.lib.vits_op_conv1d(pk0.data_ptr(), b0.data_ptr(), C, C, 3, 1, 0, p, xr.data_ptr(), n, L, 0, 0, 0, 0,
+                                     staged.data_ptr(), N.F_IN_LRELU | N.F_OUT_STAGED, 1.0, 0.1, stream), "first conv")
+        N.check(N.lib.vits_op_conv1d(pk.data_ptr(), b.data_ptr(), C, C, k, dil, 0, p, staged.data_ptr(), n, L, 0, 0, 0,
+                                     xr.data_ptr() if flags & N.F_RES else 0, out.data_ptr(), flags, 1.0, 0.1, stream),
+                "second conv")
+        return out
+
+    def values(t):
+        """fp32 values of one batch row of the result (a staged result is bf16 [C/8][L][8] in the row's first half)."""
+        if kind != "staged_out":
+            return t
+        v = t.contiguous().reshape(-1)[:C * L // 2].contiguous().view(torch.bfloat16).reshape(C // 8, L, 8).float()
+        return v.permute(0, 2, 1).reshape(C, L)
+
+    whole = run(x, init.clone())
+    if kind == "staged_out":                            # rows of a staged batch are packed back to back, 2 bytes a value
+        whole_rows = whole.reshape(-1).view(torch.bfloat16)[:B * C * L].reshape(B, C // 8, L, 8).float()
+    for i in (0, 9, 15):
+        row = run(x[i:i + 1].contiguous(), init[i:i + 1].clone())
+        torch.cuda.synchronize()
+        if kind == "staged_out":
+            d = (values(row[0]) - whole_rows[i].permute(0, 2, 1).reshape(C, L)).abs()
+            assert d.max() <= 0.04 and (d > 0).float().mean() < 1e-3      # isolated one-step bf16 differences only
+        else:
+            assert (row[0] - whole[i]).abs().max() < 1e-5
+    if kind != "staged_out":
+        xc = x[:2].cpu()
+        t = rq(F.leaky_relu(F.conv1d(rq(F.leaky_relu(xc, 0.1), p), rq(w0, p), b0.cpu(), padding=1), 0.1), p)
+        ref = F.conv1d(t, rq(w, p), b.cpu(), padding=(k - 1) // 2 * dil, dilation=dil)
+        if flags & N.F_RES:
+            ref = ref + xc
+        if flags & N.F_ACCUM:
+            ref = ref + init[:2].cpu()
+        assert (whole[:2].cpu() - ref).abs().max() < 2e-2       # a bf16 rounding of the intermediate can flip on its last bit
+
+
 @pytest.mark.parametrize("C,k,dil,L,B,acc", [(32, 3, 1, 1000, 2, False), (32, 7, 3, 3000, 2, True),
                                              (32, 11, 5, 2500, 3, False), (32, 11, 1, 224, 1, True),
                                              (32, 3, 5, 225, 2, False), (32, 7, 5, 50, 2, False),

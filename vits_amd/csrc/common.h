@@ -196,6 +196,10 @@ hipError_t launch_energy_math(const float* in, bool in_is_raw, float scale, floa
 hipError_t launch_sample(const float* stats, const float* noise, float noise_scale, float* z_p, float* z, int B, int C,
                          int L, hipStream_t s, const int* lengths = nullptr);
 // x [B, C, L] fp32 -> staged f16x2 operand format [B][C/8][2 planes][L][8 fp16] of leaky-relu(x * scale, slope)
+// the same for the staged bf16 format ([B][C/8][L] units of eight bf16, round to nearest even)
+hipError_t launch_stage_bf16(const float* x, float* out, int B, int C, int L, float scale, float slope, hipStream_t s);
+// a staged-input plain bf16 conv of this shape at this batch and length runs on the LDS-DMA kernel
+bool conv_takes_glb(const ConvDesc& d, int B, int L);
 hipError_t launch_stage_f16x2(const float* x, float* out, int B, int C, int L, float scale, float slope, int* range_flag,
                               hipStream_t s);
 // length regulator

@@ -100,6 +100,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // f16x2 operands are clamped to the fp16 range at conversion; a caller that wants to know passes a device word, and
 // every thread that clamped a value ORs 1 into it (a not-taken branch otherwise).
@@ -136,6 +137,24 @@ __device__ __forceinline__ void staged_f16x2_store(const ConvArgs& a, const floa
   }
 }
 
+// The same for the staged bf16 format [C/8][L] of 16-byte units (eight bf16): leaky-relu(out_slope), round to nearest.
+__device__ __forceinline__ void staged_bf16_store(const ConvArgs& a, const float (&fv)[16], uint2* out_b, int mt, int par,
+                                                  int t) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float e = fv[4 * g + q];
+      v[q] = fmaxf(e, e * a.out_slope);
+    }
+    uint2 o;
+    o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+    o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+    out_b[((long long)(mt * 4 + g) * a.L + t) * 2 + par] = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Epilogue shared by both arithmetic modes (the 32x32 C/D layout does not depend on the operand type).
 // Addresses are a wave-uniform row base (scalar registers) plus ONE per-lane element offset shared by all rows.
@@ -148,8 +167,9 @@ __device__ __forceinline__ void staged_f16x2_store(const ConvArgs& a, const floa
 // blocks to a CU have none to spare (with all of them built in, every such kernel spilled 48-60 bytes):
 //   EPI_LN     the deferred-LayerNorm options of ConvArgs (ln_res_*, ln_out_stats): the split-K kernel
 //   EPI_SPLIT  a second destination for the rows from split_row on: the kernels that run the flow (fp32, bf16x3)
-//   EPI_OUT2   a second, staged copy of the result: the staged-input f16x2 kernels
-constexpr int EPI_LN = 1, EPI_SPLIT = 2, EPI_OUT2 = 4;
+//   EPI_OUT2   a second, staged copy of the result: the staged-input f16x2 kernels (EPI_OUT2B: in the bf16 format, the
+//              LDS-DMA bf16 kernel)
+constexpr int EPI_LN = 1, EPI_SPLIT = 2, EPI_OUT2 = 4, EPI_OUT2B = 8;
 template <int WM, int WN, int MODE, bool RES_ALL = false, int EXTRA = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[WM][WN], const int (&mt)[WM],
                                               const bool (&mt_ok)[WM], int wn, int par, int l31, int t0, int b,
@@ -260,7 +280,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
             for (int r = 0; r < 16; ++r)
               ov[r] = (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out];
           }
-          float fv[(EXTRA & (EPI_OUT2 | EPI_LN)) ? 16 : 1];
+          float fv[(EXTRA & (EPI_OUT2 | EPI_OUT2B | EPI_LN)) ? 16 : 1];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[i][j][r] + bz[r];
@@ -270,12 +290,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
             if (flags & F_RES_SUB) v = rv[ri][j][r] - v;
             if (flags & F_ACCUM) v += ov[r];
             if (flags & F_MASK_POST) v *= m;
-            if constexpr ((EXTRA & (EPI_OUT2 | EPI_LN)) != 0) fv[r] = v;
+            if constexpr ((EXTRA & (EPI_OUT2 | EPI_OUT2B | EPI_LN)) != 0) fv[r] = v;
             (out_b + (long long)(rowu + (r & 3) + 8 * (r >> 2)) * a.out_cs)[lo_out] = v;
           }
           if constexpr ((EXTRA & EPI_OUT2) != 0) {
             if (a.out2)
               staged_f16x2_store(a, fv, reinterpret_cast<uint2*>(a.out2 + (long long)b * a.out2_bs), mt[i], par, t);
+          }
+          if constexpr ((EXTRA & EPI_OUT2B) != 0) {
+            if (a.out2)
+              staged_bf16_store(a, fv, reinterpret_cast<uint2*>(a.out2 + (long long)b * a.out2_bs), mt[i], par, t);
           }
           if constexpr (LN) {
             if (a.ln_out_stats) {
@@ -811,7 +835,6 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3_kernel(const ConvArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // helpers shared by the bf16x3 kernels below
 // ---------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // (v0, v1) -> packed bf16 pairs h, m, l with v = h + m + l exactly (low half = v0)
 __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
@@ -1608,6 +1631,227 @@ __global__ __launch_bounds__(256, 2) void conv_gl_kernel(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// PREC_BF16 with a staged input, every operand through LDS by LDS-DMA (conv_glb_kernel): conv_gl_kernel's data path
+// with one operand plane.  With one product a tap, a 64 x 64 wave tile of the register-staging kernel asks the vector
+// cache for half a kilobyte of weight fragments per MFMA -- all it delivers -- and every wave of a block fetches the
+// same ones; here a block's weights cross the load path once.
+//
+// The staged bf16 tensor is [C/8][L][8]: one run over time per 8-channel group, so the four waves of a block copy the
+// four groups of a PAIR of 16-channel chunks, and a step is (chunk pair, tap): the weights of both chunks at that tap
+// (two runs of the packed stream [Cin/16][tap][M/32][64 lanes][8 bf16], BM * 32 bytes each) in one ring slot, 16 MFMAs
+// per wave (64 x 128 wave tile) between two barriers.  Per output the products are summed tap by tap over a chunk
+// pair, not chunk by chunk as in conv_bf16_kernel: the same products, another fp32 summation order.
+// ---------------------------------------------------------------------------------------------------------
+// one step's operand fragments: weights a[h][i] (chunk h of the pair, m-tile i), activations b[h][j] (n-tile j)
+struct GlbFrags {
+  gl_u32x4 a00, a01, a10, a11, b00, b01, b02, b03, b10, b11, b12, b13;
+};
+
+template <int WN, int WGM, int WGN, int K, int D, int A>
+__global__ __launch_bounds__(256, 2) void conv_glb_kernel(const ConvArgs a) {
+  constexpr int WM = 2;
+  constexpr int BM = 64 * WGM, BN = 32 * WN * WGN;
+  static_assert(WN == 2 || WN == 4, "wave tile 64 x 64 or 64 x 128");
+  constexpr int S = D + 1, NBUF = A + 1;
+  constexpr int NCOLS = BN + MAX_HALO;           // tile columns: a multiple of 64, halo included
+  constexpr int HP = BM / 32;                    // 64-unit pieces of one chunk's weights (one per m-tile)
+  constexpr int WU = 2 * HP * 64;                // 16-byte units of one step's weights (both chunks of the pair)
+  constexpr int WPK = WU / 64 / 4;               // weight DMA instructions per wave and step
+  constexpr int APC = NCOLS / 64;                // activation DMA instructions per wave and chunk pair (wave w: group w)
+  static_assert(WGM * WGN == 4, "four waves per block");
+  static_assert(A * K >= D, "an activation tile must have left the request window when it is first read");
+  static_assert(WU % 256 == 0 && NCOLS % 64 == 0, "whole wave-instructions");
+  static_assert(HP * 1024 + 1024 < 65536 && 3 * NCOLS * 16 + 2048 < 65536, "fragment offsets fit the offset field");
+
+  extern __shared__ __attribute__((aligned(16))) uint4 gl_lds[];
+  uint4* wq = gl_lds;                            // [S][2 chunks][BM/32][64 lanes]
+  uint4* xq = gl_lds + S * WU;                   // [NBUF][2 chunks][2 halves][NCOLS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int par = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z;
+  const int t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
+  const int mt0 = blockIdx.y * HP;
+  int mt[WM];
+  bool mt_ok[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    mt[i] = mt0 + wm * WM + i;
+    mt_ok[i] = true;                             // the launcher only takes M % BM == 0
+  }
+  const int npairs = a.Cin / 32;
+  const int total = npairs * K;
+  const int tstart = t0 + a.min_off;
+  const int dil = a.tstep[0];
+
+  // ---- DMA requests ----
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.Cin * K * a.M * 2, 0x00020000);
+  const uint4* xs_b = reinterpret_cast<const uint4*>(a.x + (long long)b * a.x_bs);
+  auto issue_w = [&](int s, int slot) __attribute__((always_inline)) {
+    const int sc = s < total ? s : total - 1;
+    const int pr = sc / K, k = sc - pr * K;
+#pragma unroll
+    for (int j = 0; j < WPK; ++j) {
+      const int piece = wave + 4 * j;            // of the slot: chunk h = piece / HP, m-tile piece % HP
+      const int h = piece / HP, mi = piece - h * HP;
+      const int unit0 = (((2 * pr + h) * K + k) * a.mt_total + mt0 + mi) * 64;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(wq + slot * WU + piece * 64), 16,
+                                               (unit0 + lane) * 16, 0, 0, 0);
+    }
+  };
+  auto issue_x = [&](int c, int buf) __attribute__((always_inline)) {
+    const int cc = c < npairs ? c : npairs - 1;
+    // this wave's run: channel group 4 * cc + wave (chunk wave >> 1 of the pair, half wave & 1) over time, one buffer
+    // descriptor, so that t < 0 and t >= L are out of range and read as zero
+    const uint4* slab = xs_b + (long long)(cc * 4 + wave) * a.L;
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(slab), 0, a.L * 16, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < APC; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(xq + (buf * 4 + wave) * NCOLS + 64 * j), 16,
+                                               (tstart + 64 * j + lane) * 16, 0, 0, 0);
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- the requests of the steps before the first one, in the loop's own order ----
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    if ((c - A) * K < -D) issue_x(c, c % NBUF);
+#pragma unroll
+  for (int v = -D; v < 0; ++v) {
+    if (gl_floor_mod(v, K) == 0) issue_x(gl_floor_div(v, K) + A, (gl_floor_div(v, K) + A) % NBUF);
+    issue_w(v + D, (v + D) % S);
+  }
+
+  int slot_rd = 0, slot_wr = D % S;              // ring slot of the current step, and of step + D
+  int buf_rd = 0, buf_wr = A % NBUF;             // buffer of the current chunk pair, and of pair + A
+  // Byte addresses: weight fragment (chunk h, m-tile i) of a slot at a_addr + (h * HP + i) * 1024; activation unit
+  // (chunk h, half par, column) at b_addr + h * 2 * NCOLS * 16 + 512 * j, tap k a further k * dil * 16.
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_void*)gl_lds;
+  const unsigned a_addr = lds_base + (unsigned)(((wm * WM) * 64 + lane) * 16);
+  const unsigned b_addr = lds_base + (unsigned)((S * WU + par * NCOLS + wn * 32 * WN + l31) * 16);
+  GlbFrags f0, f1;
+  {
+    const gl_u32x4 z = {0u, 0u, 0u, 0u};
+    f1.a00 = f1.a01 = f1.a10 = f1.a11 = f1.b00 = f1.b01 = f1.b02 = f1.b03 = f1.b10 = f1.b11 = f1.b12 = f1.b13 = z;
+    f0 = f1;
+  }
+  auto read_frags = [&](GlbFrags& f, unsigned wa, unsigned xk) __attribute__((always_inline)) {
+    asm volatile(
+        "ds_read_b128 %0, %4\n\t"
+        "ds_read_b128 %1, %4 offset:1024\n\t"
+        "ds_read_b128 %2, %4 offset:%c5\n\t"
+        "ds_read_b128 %3, %4 offset:%c6"
+        : "=&v"(f.a00), "=&v"(f.a01), "=&v"(f.a10), "=&v"(f.a11)
+        : "v"(wa), "i"(HP * 1024), "i"(HP * 1024 + 1024)
+        : "memory");
+    asm volatile(
+        "ds_read_b128 %0, %4\n\t"
+        "ds_read_b128 %1, %4 offset:512\n\t"
+        "ds_read_b128 %2, %4 offset:%c5\n\t"
+        "ds_read_b128 %3, %4 offset:%c6"
+        : "=&v"(f.b00), "=&v"(f.b01), "=&v"(f.b10), "=&v"(f.b11)
+        : "v"(xk), "i"(2 * NCOLS * 16), "i"(2 * NCOLS * 16 + 512)
+        : "memory");
+    if constexpr (WN == 4)
+      asm volatile(
+          "ds_read_b128 %0, %4 offset:1024\n\t"
+          "ds_read_b128 %1, %4 offset:1536\n\t"
+          "ds_read_b128 %2, %4 offset:%c5\n\t"
+          "ds_read_b128 %3, %4 offset:%c6"
+          : "=&v"(f.b02), "=&v"(f.b03), "=&v"(f.b12), "=&v"(f.b13)
+          : "v"(xk), "i"(2 * NCOLS * 16 + 1024), "i"(2 * NCOLS * 16 + 1536)
+          : "memory");
+  };
+  // the products of a step, first chunk of the pair first, from a register set whose reads have been waited for
+  auto mma2 = [&](const GlbFrags& f) __attribute__((always_inline)) {
+    const gl_u32x4 Af[2][WM] = {{f.a00, f.a01}, {f.a10, f.a11}};
+    gl_u32x4 Bf[2][WN];
+    Bf[0][0] = f.b00; Bf[0][1] = f.b01; Bf[1][0] = f.b10; Bf[1][1] = f.b11;
+    if constexpr (WN == 4) { Bf[0][2] = f.b02; Bf[0][3] = f.b03; Bf[1][2] = f.b12; Bf[1][3] = f.b13; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Af[h][i]),
+                                                              __builtin_bit_cast(bf16x8, Bf[h][j]), acc[i][j], 0, 0, 0);
+  };
+  int s = 0;
+  for (int c0 = 0; c0 < npairs; c0 += 2) {         // two chunk pairs a trip: the register sets swap at compile time
+    auto step = [&](auto jj) __attribute__((always_inline)) {
+      constexpr int j = decltype(jj)::value;
+      constexpr int k = j % K;
+      constexpr int allowed = (D - 1) * WPK + APC * gl_tap0_in_window(k, K, D);
+      GlbFrags& cur = (j & 1) ? f1 : f0;
+      GlbFrags& prev = (j & 1) ? f0 : f1;
+      // the wait names every register of the previous set, so nothing touches them before their reads have landed
+      if constexpr (WN == 4)
+        asm volatile("s_waitcnt vmcnt(%12) lgkmcnt(0)"
+                     : "+v"(prev.a00), "+v"(prev.a01), "+v"(prev.a10), "+v"(prev.a11), "+v"(prev.b00), "+v"(prev.b01),
+                       "+v"(prev.b10), "+v"(prev.b11), "+v"(prev.b02), "+v"(prev.b03), "+v"(prev.b12), "+v"(prev.b13)
+                     : "n"(allowed)
+                     : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)"
+                     : "+v"(prev.a00), "+v"(prev.a01), "+v"(prev.a10), "+v"(prev.a11), "+v"(prev.b00), "+v"(prev.b01),
+                       "+v"(prev.b10), "+v"(prev.b11)
+                     : "n"(allowed)
+                     : "memory");
+      __builtin_amdgcn_s_barrier();
+      read_frags(cur, a_addr + (unsigned)(slot_rd * WU * 16),
+                 b_addr + (unsigned)(buf_rd * 4 * NCOLS * 16) + (unsigned)(k * dil * 16));
+      __builtin_amdgcn_sched_barrier(0);
+      if (j > 0 || c0 > 0) mma2(prev);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (k == 0) issue_x(c0 + j / K + A, buf_wr);
+      issue_w(s + D, slot_wr);
+      ++s;
+      slot_rd = slot_rd + 1 == S ? 0 : slot_rd + 1;
+      slot_wr = slot_wr + 1 == S ? 0 : slot_wr + 1;
+      if constexpr (k == K - 1) {
+        buf_rd = buf_rd + 1 == NBUF ? 0 : buf_rd + 1;
+        buf_wr = buf_wr + 1 == NBUF ? 0 : buf_wr + 1;
+      }
+    };
+    gl_static_for<0, 2 * K>(step);
+  }
+  // the last step's products (an even number of steps: its fragments are in the second set)
+  if constexpr (WN == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f1.a00), "+v"(f1.a01), "+v"(f1.a10), "+v"(f1.a11), "+v"(f1.b00), "+v"(f1.b01), "+v"(f1.b10),
+                   "+v"(f1.b11), "+v"(f1.b02), "+v"(f1.b03), "+v"(f1.b12), "+v"(f1.b13)
+                 :
+                 : "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f1.a00), "+v"(f1.a01), "+v"(f1.a10), "+v"(f1.a11), "+v"(f1.b00), "+v"(f1.b01), "+v"(f1.b10),
+                   "+v"(f1.b11)
+                 :
+                 : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  mma2(f1);
+  // nothing of this block may still be on its way into LDS when the block's LDS is handed to the next one
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (a.flags & F_OUT_STAGED) {
+    conv_epilogue_staged<WM, WN, 1>(a, acc, mt, mt_ok, wn, par, l31, t0, b);
+    return;
+  }
+  conv_epilogue<WM, WN, MODE_PLAIN, WN == 2, EPI_OUT2B>(a, acc, mt, mt_ok, wn, par, l31, t0, b, a.lengths ? a.lengths[b] : 0x7fffffff);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 ProfTicket prof_begin(hipStream_t stream) {
@@ -1633,12 +1877,13 @@ void prof_end(const ProfTicket& t, const char* name, bool gate, const ConvArgs& 
   // accumulated-output reads where the epilogue has them, the packed weights once
   const double outs = (gate ? 0.5 : 1.0) * a.M;
   const int reads = ((a.flags & (F_RES | F_RES_SUB)) ? 1 : 0) + ((a.flags & F_ACCUM) ? 1 : 0);
-  const double wbytes = strstr(name, "conv_mfma") || strstr(name, "conv_f16x2") || strstr(name, "conv_gl") ||
-                                strstr(name, "resblock_pair") ? 4.0
-                        : strstr(name, "conv_bf16_kernel") ? 2.0 : 6.0;
-  const double sb = strstr(name, "conv_bf16_kernel") ? 2.0 : 4.0;           // bytes per staged element
+  const bool plain_bf16 = strstr(name, "conv_bf16_kernel") || strstr(name, "conv_glb_bf16");
+  const double wbytes = plain_bf16 ? 2.0
+                        : strstr(name, "conv_mfma") || strstr(name, "conv_f16x2") || strstr(name, "conv_gl") ||
+                                strstr(name, "resblock_pair") ? 4.0 : 6.0;
+  const double sb = plain_bf16 ? 2.0 : 4.0;                                   // bytes per staged element
   const double in_b = (a.flags & F_IN_STAGED) ? sb : 4.0, out_b = (a.flags & F_OUT_STAGED) ? sb : 4.0;
-  c.bytes += (double)a.L * a.B * (in_b * a.Cin + outs * (out_b + 4.0 * reads + (a.out2 ? 4.0 : 0.0))) + wbytes * a.M * a.Cin * a.K;
+  c.bytes += (double)a.L * a.B * (in_b * a.Cin + outs * (out_b + 4.0 * reads + (a.out2 ? sb : 0.0))) + wbytes * a.M * a.Cin * a.K;
   c.count += 1;
   c.pending.emplace_back(t.e0, t.e1);
 }
@@ -1703,8 +1948,67 @@ static hipError_t launch_b3(ConvArgs& a, hipStream_t stream) {
   });
 }
 
+template <int WN, int WGM, int WGN, int K, int D, int A>
+static hipError_t launch_glb_cfg(ConvArgs& a, hipStream_t stream) {
+  constexpr int BM = 64 * WGM, BN = 32 * WN * WGN;
+  constexpr size_t lds = ((size_t)(D + 1) * BM * 4 + (size_t)(A + 1) * 4 * (BN + MAX_HALO)) * sizeof(uint4);
+  static_assert(lds <= 80 * 1024, "two blocks to a CU");
+  static bool attr_set = false;                  // more than 64 KiB of dynamic LDS has to be asked for once per kernel
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_glb_kernel<WN, WGM, WGN, K, D, A>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid((a.L + BN - 1) / BN, a.M / BM, a.B);
+  char name[96];
+  snprintf(name, sizeof name, "conv_glb_bf16_kernel<%d,%d,%d,%d,%d,%d>", WN, WGM, WGN, K, D, A);
+  return timed_launch(name, false, a, stream, [&] {
+    hipLaunchKernelGGL((conv_glb_kernel<WN, WGM, WGN, K, D, A>), grid, dim3(256), lds, stream, a);
+  });
+}
+
+// Staged-input plain bf16 convs of the generator (3, 7 or 11 taps, rows in 128s, channels in 64s) whose grid fills the
+// chip go to the LDS-DMA kernel; VITS_CONV_GLB=0 keeps them on the register-staging kernel (A/B measurements).
+// shape and grid of a launch the kernel takes: 0 = none, else the block tile width
+static int glb_tile_width(int M, int Cin, int K, int dil, int B, int L) {
+  static const bool on = !(getenv("VITS_CONV_GLB") && getenv("VITS_CONV_GLB")[0] == '0');
+  if (!on || M % 128 || Cin % 64 || (K != 3 && K != 7 && K != 11) || dil < 1) return 0;
+  if ((long long)Cin * K * M * 2 >= (1LL << 31) || (long long)L * 16 >= (1LL << 31)) return 0;
+  auto blocks_of = [&](int bn) { return (long long)((L + bn - 1) / bn) * (M / 128) * B; };
+  const long long slots = 2LL * device_cu_count();            // two blocks to a CU
+  const bool wide = blocks_of(256) > slots;
+  if (blocks_of(wide ? 256 : 128) <= slots / 2) return 0;
+  return wide ? 256 : 128;
+}
+
+// A staged-input plain bf16 conv of this shape and size runs on the LDS-DMA kernel (which is also the one that can
+// write the second, staged copy of its result): what the generator asks before it stages a stage's input.
+bool conv_takes_glb(const ConvDesc& d, int B, int L) {
+  return d.prec == PREC_BF16 && d.mode == MODE_PLAIN && glb_tile_width(d.M, d.Cin, d.K, d.tstep[0], B, L) > 0;
+}
+
+static bool try_launch_glb(ConvArgs& a, hipStream_t stream, hipError_t& err) {
+  if (!(a.flags & F_IN_STAGED) || a.in_cbias || a.cbias || (a.flags & (F_IN_MASK | F_IN_LRELU)) || a.split_row) return false;
+  const int width = glb_tile_width(a.M, a.Cin, a.K, a.tstep[0], a.B, a.L);
+  if (!width) return false;
+  const bool wide = width == 256;
+  if (wide)
+    err = a.K == 3 ? launch_glb_cfg<4, 2, 2, 3, 3, 1>(a, stream) : a.K == 7 ? launch_glb_cfg<4, 2, 2, 7, 3, 1>(a, stream)
+                                                                           : launch_glb_cfg<4, 2, 2, 11, 3, 1>(a, stream);
+  else
+    err = a.K == 3 ? launch_glb_cfg<2, 2, 2, 3, 4, 2>(a, stream) : a.K == 7 ? launch_glb_cfg<2, 2, 2, 7, 4, 1>(a, stream)
+                                                                           : launch_glb_cfg<2, 2, 2, 11, 4, 1>(a, stream);
+  return true;
+}
+
 template <int WM, int WN, int WGM, int WGN, int MODE>
 static hipError_t launch_b1(ConvArgs& a, hipStream_t stream) {
+  if constexpr (MODE == MODE_PLAIN) {
+    hipError_t err = hipSuccess;
+    if (try_launch_glb(a, stream, err)) return err;
+  }
+  if (a.out2) return hipErrorInvalidValue;      // only the LDS-DMA kernel writes the second copy (see conv_takes_glb)
   constexpr int BN = 32 * WN * WGN;
   a.width = BN + (a.width);
   a.rs = a.width;                    // columns per half slab
@@ -2295,7 +2599,7 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   if (a.split_row && (d.mode != MODE_PLAIN || a.split_row % 64 || a.split_row >= M || !a.out_hi || a.out2 ||
                       (a.flags & (F_OUT_STAGED | F_IN_STAGED)) || ((a.flags | a.flags_hi) & F_RES_SUB)))
     return hipErrorInvalidValue;
-  if (a.out2 && (d.mode != MODE_PLAIN || p != PREC_F16X2 || (a.flags & F_OUT_STAGED) || !(a.flags & F_IN_STAGED)))
+  if (a.out2 && (d.mode != MODE_PLAIN || (p != PREC_F16X2 && p != PREC_BF16) || (a.flags & F_OUT_STAGED) || !(a.flags & F_IN_STAGED)))
     return hipErrorInvalidValue;                       // the staged-input f16x2 kernels write it
   if (a.split_row && p != PREC_F32 && p != PREC_BF16X3) return hipErrorInvalidValue;       // the kernels that run the flow
   // deferred LayerNorm: the bf16x3 kernels' 64-row wave tiles only; statistics are per 64-channel unit

@@ -1005,6 +1005,39 @@ hipError_t launch_stage_f16x2(const float* x, float* out, int B, int C, int L, f
   return hipGetLastError();
 }
 
+// The same for the plain-bf16 arithmetic: y = leaky-relu(x * scale, slope) rounded to nearest-even bf16, written as
+// [B][C/8][L] 16-byte units of eight channels -- the values conv_bf16_kernel converts at staging.
+typedef __bf16 st_bf16x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void stage_bf16_kernel(const float* __restrict__ x, uint4* __restrict__ out, int C, int L,
+                                                         float scale, float slope) {
+  const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  if (t >= L) return;
+  const float* xb = x + ((long long)b * C + cg * 8) * L + t;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = xb[(long long)i * L];
+  unsigned p[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st_f32x2 e;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float y = v[2 * i + u] * scale;
+      e[u] = fmaxf(y, y * slope);
+    }
+    p[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, st_bf16x2));
+  }
+  out[((long long)b * (C / 8) + cg) * L + t] = make_uint4(p[0], p[1], p[2], p[3]);
+}
+
+hipError_t launch_stage_bf16(const float* x, float* out, int B, int C, int L, float scale, float slope, hipStream_t s) {
+  if (B <= 0 || C <= 0 || C % 8 || L <= 0 || B > 65535 || C / 8 > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(stage_bf16_kernel, dim3((L + 255) / 256, C / 8, B), dim3(256), 0, s, x,
+                     reinterpret_cast<uint4*>(out), C, L, scale, slope);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // length regulator (reference models.py:426-455): phoneme p of row b is repeated max(int(dur[b][p]), 0) times.
 // plan: integer durations -> inclusive prefix sum per row (block scan in LDS);  gather: per frame, binary search

@@ -203,7 +203,7 @@ ConvArgs conv_simple_args(const ConvDesc& d, const float* x, float* out, int B, 
                           const float* in_cbias = nullptr, int in_cbias_bs = 0, float in_scale = 1.f, float in_slope = 1.f,
                           float out_slope = 1.f, float* out2 = nullptr) {
   ConvArgs a = base_args(x, (long long)d.Cin * L, L, out, (long long)d.cout * L * d.up, L * d.up, B, L, lengths, flags);
-  a.out2 = out2; a.out2_bs = (long long)d.cout * L;          // staged f16x2 copy: as many bytes per element as fp32
+  a.out2 = out2; a.out2_bs = staged_row_floats(d.prec, d.cout, L);   // staged copy: f16x2 as many bytes as fp32, bf16 half
   if (flags & F_IN_STAGED) a.x_bs = staged_row_floats(d.prec, d.Cin, L);
   if (flags & F_OUT_STAGED) a.out_bs = staged_row_floats(d.prec, d.cout, L);
   a.out_slope = out_slope;
@@ -1020,7 +1020,9 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
     // f16x2 arithmetic: every conv of an unfused pair takes its input in the staged operand format (leaky-relu applied,
     // split into fp16 h / l) -- x is converted once for all chains here, and the second conv of a pair writes its
     // result twice, as fp32 (the residual of the next pair) and staged (the input of the next pair's first conv).
-    bool stage_x = false;
+    // Plain-bf16 arithmetic: the same where the stage's convs run on the LDS-DMA kernel (the one that writes the second
+    // copy), i.e. for rows in 128s at sizes that fill the chip; decided per stage, for every chain at once.
+    bool stage_x = false, stage_bf16 = false;
     const bool single = c.resblock == 2;            // modules.ResBlock2 (reference modules.py:228-252)
     for (int j = 0; j < nk && staged_pairs_enabled() && !single; ++j) {
       const ResBlock& rb = m->rbs[i * nk + j];
@@ -1028,8 +1030,18 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
       for (int q = 0; q < nd && fused; ++q) fused = pair_profitable(rb.c1[q], rb.c2[q]);
       if (!fused && rb.c1[0].prec == PREC_F16X2 && rb.c2[0].prec == PREC_F16X2) stage_x = true;
     }
+    if (!stage_x && staged_pairs_enabled() && !single) {
+      stage_bf16 = true;
+      for (int j = 0; j < nk && stage_bf16; ++j) {
+        const ResBlock& rb = m->rbs[i * nk + j];
+        for (int q = 0; q < nd && stage_bf16; ++q)
+          stage_bf16 = conv_takes_glb(rb.c1[q], B, L) && conv_takes_glb(rb.c2[q], B, L);
+      }
+    }
     if (stage_x)
       HIP_TRY(launch_stage_f16x2(X, XG, B, m->rbs[i * nk].c1[0].Cin, L, 1.f, 0.1f, g_range_flag, s));
+    if (stage_bf16)
+      HIP_TRY(launch_stage_bf16(X, XG, B, m->rbs[i * nk].c1[0].Cin, L, 1.f, 0.1f, s));
     if (n_side > 0) {
       HIP_TRY(hipEventRecord(m->ev_fork, s));
       for (int j = 0; j < n_side; ++j) HIP_TRY(hipStreamWaitEvent(m->side[j], m->ev_fork, 0));
@@ -1080,7 +1092,8 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
         // staging; half the bytes in bf16 mode).
         const int p1 = rb.c1[q].prec;
         const bool staged = staged_pairs_enabled() && p1 == rb.c2[q].prec && (p1 == PREC_BF16 || p1 == PREC_F16X2);
-        const bool staged_in = staged && p1 == PREC_F16X2 && stage_x;      // the first conv's input is staged as well
+        // the first conv's input is staged as well
+        const bool staged_in = staged && ((p1 == PREC_F16X2 && stage_x) || (p1 == PREC_BF16 && stage_bf16));
         const float* c1_in = staged_in ? (q == 0 ? XG : YG[j]) : yin;
         TRY(conv_simple(rb.c1[q], c1_in, Tt[j], B, L, nullptr,
                         (staged_in ? F_IN_STAGED : F_IN_LRELU) | (staged ? F_OUT_STAGED : 0), sj, nullptr, nullptr, 0,
