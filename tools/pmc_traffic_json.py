@@ -27,6 +27,7 @@ def per_kernel(path, counter):
             # (and its fourth the row tiles per wave, which the timing rows leave out)
             name = re.sub(r"resblock_pair_kernel<(\d+),(\d+),2(,\d+)?>", r"resblock_pair_kernel<\1,\2>", name)
             name = re.sub(r"resblock_pair_kernel<(\d+),(\d+),1(,\d+)?>", r"resblock_pair_bf16_kernel<\1,\2>", name)
+            name = name.replace("conv_glb_kernel<", "conv_glb_bf16_kernel<")     # the timing row names its arithmetic
             name = name.replace(",false,0>", ">").replace(",true>", ",staged>").replace(",false>", ">")
             acc[name].append(float(r["Counter_Value"]) * 1024.0)
     return acc
