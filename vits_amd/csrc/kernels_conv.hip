@@ -1973,11 +1973,12 @@ static hipError_t launch_glb_cfg(ConvArgs& a, hipStream_t stream) {
 // shape and grid of a launch the kernel takes: 0 = none, else the block tile width
 static int glb_tile_width(int M, int Cin, int K, int dil, int B, int L) {
   static const bool on = !(getenv("VITS_CONV_GLB") && getenv("VITS_CONV_GLB")[0] == '0');
-  if (!on || M % 128 || Cin % 64 || (K != 3 && K != 7 && K != 11) || dil < 1) return 0;
+  if (!on || M % 64 || Cin % 64 || (K != 3 && K != 7 && K != 11) || dil < 1) return 0;
   if ((long long)Cin * K * M * 2 >= (1LL << 31) || (long long)L * 16 >= (1LL << 31)) return 0;
-  auto blocks_of = [&](int bn) { return (long long)((L + bn - 1) / bn) * (M / 128) * B; };
+  const bool tall = M % 128 == 0;                             // 128-row blocks, else 64 x 256
+  auto blocks_of = [&](int bn) { return (long long)((L + bn - 1) / bn) * (M / (tall ? 128 : 64)) * B; };
   const long long slots = 2LL * device_cu_count();            // two blocks to a CU
-  const bool wide = blocks_of(256) > slots;
+  const bool wide = !tall || blocks_of(256) > slots;
   if (blocks_of(wide ? 256 : 128) <= slots / 2) return 0;
   return wide ? 256 : 128;
 }
@@ -1993,7 +1994,10 @@ static bool try_launch_glb(ConvArgs& a, hipStream_t stream, hipError_t& err) {
   const int width = glb_tile_width(a.M, a.Cin, a.K, a.tstep[0], a.B, a.L);
   if (!width) return false;
   const bool wide = width == 256;
-  if (wide)
+  if (a.M % 128)
+    err = a.K == 3 ? launch_glb_cfg<2, 1, 4, 3, 4, 2>(a, stream) : a.K == 7 ? launch_glb_cfg<2, 1, 4, 7, 4, 1>(a, stream)
+                                                                           : launch_glb_cfg<2, 1, 4, 11, 4, 1>(a, stream);
+  else if (wide)
     err = a.K == 3 ? launch_glb_cfg<4, 2, 2, 3, 3, 1>(a, stream) : a.K == 7 ? launch_glb_cfg<4, 2, 2, 7, 3, 1>(a, stream)
                                                                            : launch_glb_cfg<4, 2, 2, 11, 3, 1>(a, stream);
   else
