@@ -2676,6 +2676,10 @@ constexpr int PAIR_YOFF = 16;
 // memory returns in order within a CU, so behind the other blocks' streaming x loads it takes ~2000 cycles instead of
 // ~560; fetched only one tap ahead of its MFMAs (192 cycles a tap) the matrix pipe sat idle most of the time.
 constexpr int PAIR_AHEAD = 3;
+// The two-row-tile build (64 channels, one plane) has two blocks to a CU instead of three to cover a fragment's round
+// trip, and registers to spare: seven taps ahead (per launch at 64 x 10 s, ring of 3 / 5 / 7: k = 11 4.60 / 4.01 / 3.83 ms,
+// k = 7 3.24 / 2.90 / 2.90).  The one-row-tile bf16 build gains nothing from a deeper ring (8: k = 7 6 % slower).
+constexpr int PAIR_TALL_AHEAD = 7;
 
 // NP: operand planes.  2: PREC_F16X2 (fp16 h / l, three products a tap).  1: PREC_BF16 (operands rounded to bf16, one
 // product a tap; the same staging, the same order of additions as conv_bf16_kernel with a staged intermediate).
@@ -2691,7 +2695,7 @@ __global__ __launch_bounds__(256, WR == 2 ? 2 : 3) void resblock_pair_kernel(con
   static_assert(MT % WR == 0, "whole waves in rows");
   constexpr int WGM = MT / WR, WGN = 4 / WGM, W1 = 64 * WGN, BN = W1 - 32, NCH = 2 * MT;
   constexpr int CPT = NCH * W1 / 256;                       // 16-channel chunks of its column a thread loads and keeps
-  constexpr int NT = NCH * K, D = PAIR_AHEAD;               // taps per conv; depth of the weight ring
+  constexpr int NT = NCH * K, D = WR == 2 ? PAIR_TALL_AHEAD : PAIR_AHEAD;               // taps per conv; depth of the weight ring
   constexpr int OP = BN + 8;                                // row pitch of the result tile in LDS (floats)
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
