@@ -115,10 +115,11 @@ def kernel_peak_tflops(name):
     return PEAK_BF16X3_TFLOPS
 
 
-def roofline_pass(net, run_once, steps, device, traffic_key=None, brief=False):
+def roofline_pass(net, run_once, steps, device, traffic_key=None, top=3, label=None):
     """Per-launch HIP-event timing of every conv kernel over `steps` calls of run_once() (plain infer calls: the
     library keeps the generator on one stream while timing is on, so intervals do not overlap); returns the roofline
-    object of the instantiation with the largest summed time."""
+    object of the instantiation with the largest summed time.  The object names the `top` kernels by summed time; the
+    whole per-kernel table goes to stderr as a JSON line of its own, so that the result line stays a few kilobytes."""
     from vits_amd import _native as N
     N.lib.vits_profile_reset()
     N.lib.vits_profile_enable(1)
@@ -151,7 +152,10 @@ def roofline_pass(net, run_once, steps, device, traffic_key=None, brief=False):
     kernels = [dict(kernel=r["name"], tflops=round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
                     gbps=round(r["bytes"] / (r["ms"] * 1e-3) / 1e9), ms_per_step=round(r["ms"] / steps, 3),
                     launches_per_step=round(r["count"] / steps, 2)) for r in rows]
-    roof["all_conv_kernels"] = kernels[:4] if brief else kernels
+    if top:
+        roof["top_kernels"] = kernels[:top]
+    print(json.dumps({"conv_kernel_table": label or "headline", "steps": steps, "kernels": kernels}), file=sys.stderr,
+          flush=True)
     return roof
 
 
@@ -159,7 +163,8 @@ def cpu_baseline(phonemes=50, frames=258, sample_utts=4, runs=2):
     """Time the CPU oracle on a bounded sample: `sample_utts` utterances of the benchmark workload's shape."""
     from oracle.mvts_oracle import OracleSynthesizer
     from vits_amd import synthetic
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    # the GPU box gives a one-GPU job 16 CPUs of a much larger host; os.cpu_count() reports the host's
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
     sd = synthetic.synthetic_state_dict(include_enc_q=False)
     orc = OracleSynthesizer(sd)
     b = synthetic.make_batch(1, [phonemes] * sample_utts, [frames] * sample_utts)
@@ -174,9 +179,8 @@ def cpu_baseline(phonemes=50, frames=258, sample_utts=4, runs=2):
         best = min(best, time.perf_counter() - t0)
     return dict(value=round(b.audio_seconds / best, 3), unit="audio-s/s", cores=torch.get_num_threads(),
                 host_cores=os.cpu_count(), kind="port",
-                sample=f"{sample_utts} utterances x {frames} frames ({frames * 512 / 44100:.1f} s each) of the "
-                       f"benchmark workload, fp32, best of {runs} runs after warm-up, {torch.get_num_threads()} "
-                       f"threads of the host's {os.cpu_count()} cores; PyTorch CPU oracle (oracle/mvts_oracle.py)"), out, b
+                sample=f"{sample_utts} utterances x {frames} frames of the benchmark workload, fp32, best of {runs} "
+                       f"runs after warm-up; PyTorch CPU oracle (oracle/mvts_oracle.py)"), out, b
 
 
 def dtype_of(net):
@@ -236,7 +240,7 @@ def run_corpus(net, args, device, rank, world, dist, red_dev):
         # dominant kernel over rank 0's own batches (one event-timed pass over a spread of them)
         sample = data[::max(1, len(data) // 8)]
         it = iter(sample * 1000)
-        result["roofline"] = roofline_pass(net, lambda: step(net, next(it)), len(sample), device, brief=True)
+        result["roofline"] = roofline_pass(net, lambda: step(net, next(it)), len(sample), device, label="C4")
         if world == 1 and not args.no_cpu_baseline:
             cb, _, _ = cpu_baseline(phonemes=35, frames=386, sample_utts=3)     # the corpus's median utterance
             result["cpu_baseline"] = cb
@@ -261,18 +265,17 @@ def sub_results(net, device, overlap):
     def batch_entry(name, model, batch, steps, warmup):
         d = to_device(batch, device)
         el = timed_steps(model, d, steps, warmup, overlap, device)
-        roof = roofline_pass(model, lambda: step(model, d), max(2, steps // 2), device, brief=True)
         B, P, T = batch.phonemes.shape[0], int(batch.lengths.max()), int(batch.frames.max())
+        roof = roofline_pass(model, lambda: step(model, d), max(2, steps // 2), device, top=0, label=name,
+                             traffic_key=dict(batch=B, frames=T, phonemes=P, precision=model.precision))
         flops = algorithmic_flops(batch.lengths.tolist(), batch.frames.tolist())
         out.append({"workload": name, "value": round(steps * batch.audio_seconds / el, 2), "unit": "audio-s/s",
                     "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup,
-                    "dtype": dtype_of(model), "conv_precision": model.precision,
-                    "shape": {"batch": B, "phonemes": P, "frames": T},
+                    "conv_precision": model.precision, "shape": [B, P, T],
                     "whole_path_tflops": round(steps * flops / el / 1e12, 2), "roofline": roof})
 
     c3 = synthetic.config_c3()
-    batch_entry("C3 shape: batch 64 x 160 phonemes x 861 frames (10 s each) in the default f16x2 arithmetic",
-                net, c3, 4, 1)
+    batch_entry("C3 shape (64 x 10 s) in f16x2", net, c3, 10, 2)
     # a fixed sample of the C4 corpus: every 5th of its 157 length-sorted batches (shortest and longest included)
     batches, mine, data = corpus_data(device, 10000, 64, 1, 0, every=5)
     run_steps(net, [data[-1], data[0]], overlap)
@@ -284,17 +287,17 @@ def sub_results(net, device, overlap):
     frames = sum(sum(ts) for _, ts in batches)
     it = iter(data[::4] * 1000)
     out.append({"workload": f"C4 sample: every 5th of the corpus's 157 length-sorted batches ({len(batches)} batches, "
-                            f"{sum(len(ts) for _, ts in batches)} of 10000 utterances, 88..1400 frames), one GPU",
+                            f"{sum(len(ts) for _, ts in batches)} utterances of 88..1400 frames)",
                 "value": round(frames * 512 / 44100.0 / el, 2), "unit": "audio-s/s",
                 "ms_per_step": round(el / len(data) * 1e3, 3), "steps": len(data), "warmup": 2,
-                "dtype": dtype_of(net), "conv_precision": net.precision,
+                "conv_precision": net.precision,
                 "whole_path_tflops": round(sum(algorithmic_flops(ps, ts) for ps, ts in batches) / el / 1e12, 2),
-                "roofline": roofline_pass(net, lambda: step(net, next(it)), len(data[::4]), device, brief=True)})
+                "roofline": roofline_pass(net, lambda: step(net, next(it)), len(data[::4]), device, top=0,
+                                          label="C4 sample")})
     del data
     for prec, name, batch, steps, warmup in (
-            ("bf16", "C3: batch 64 x 160 phonemes x 861 frames (10 s each), bf16 generator convs", c3, 4, 1),
-            ("bf16x3", "C2 in bf16x3 arithmetic (full fp32 range): batch 16 x 50 phonemes x 258 frames",
-             synthetic.config_c2(), 10, 2)):
+            ("bf16", "C3 (64 x 10 s), bf16 generator convs", c3, 10, 2),
+            ("bf16x3", "C2 in bf16x3 (full fp32 range)", synthetic.config_c2(), 10, 2)):
         model = build_model(device, prec)
         batch_entry(name, model, batch, steps, warmup)
         del model
@@ -318,12 +321,11 @@ def free_port():
 
 
 def spawn_ranks(args):
-    """Parent of a plain `python bench.py --gpus N`: start N children of this script, one per GPU, and wait.  Nothing
-    here initialises a GPU (device_count does not).  Rank 0's stdout is the parent's, so its JSON line is the run's."""
+    """Parent of a plain `python bench.py --gpus N`: start N children of this script, one per GPU, and wait.  The
+    parent never calls into torch.cuda (a count of the GPUs may initialise the runtime, and the ranks are started from
+    this process): a rank that finds no GPU under its LOCAL_RANK stops with its own message and the others are ended.
+    Rank 0's stdout is the parent's, so its JSON line is the run's."""
     n = args.gpus
-    if args.backend == "nccl" and torch.cuda.device_count() < n:
-        raise SystemExit(f"--gpus {n} needs {n} visible GPUs, found {torch.cuda.device_count()} "
-                         "(several ranks can share a GPU for a rehearsal with --backend gloo)")
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     procs = []
     for r in range(n):
@@ -394,6 +396,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report the wrong GPU count")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
+    if args.backend == "nccl" and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} needs a GPU per rank, this node shows "
+                         f"{torch.cuda.device_count()} (several ranks can share a GPU for a rehearsal with --backend gloo)")
     device = torch.device("cuda", local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     dist = None
@@ -506,12 +511,17 @@ def main():
                        "batch_per_gpu": args.batch, "frames": args.frames, "parallelism": f"utterance-dp{world}",
                        "front_end_overlap": overlap},
             "whole_path_tflops": round(world * args.steps * flops_step / elapsed / 1e12, 2),
-            "rtf_batch1": None if args.no_latency else round(rtf, 5),
-            "batch1_latency_ms": None if args.no_latency else round(lat[len(lat) // 2] * 1e3, 3),
-            "batch1_edit_latency_ms": None if args.no_latency else round(lat5[len(lat5) // 2] * 1e3, 3),
-            "stream_first_window_ms": None if args.no_latency else round(lat_first[len(lat_first) // 2] * 1e3, 3),
             "roofline": roofline,
         }
+        if not args.no_latency:
+            # BASELINE's metric has a second half, batch-1 RTF: it rides in `config` and, identically, at the top
+            # level (C1 = configs[0]'s utterance, C5 = configs[4]'s edit path; medians of 20 calls)
+            latency = {"rtf_batch1": round(rtf, 5), "batch1_latency_ms": round(lat[len(lat) // 2] * 1e3, 3),
+                       "batch1_edit_latency_ms": round(lat5[len(lat5) // 2] * 1e3, 3),
+                       "stream_first_window_ms": round(lat_first[len(lat_first) // 2] * 1e3, 3)}
+            result["config"].update(latency)
+            result["roofline"].update(rtf_batch1=latency["rtf_batch1"])
+            result.update(latency)
         if world == 1 and not args.no_cpu_baseline:
             # about 10-30 s of CPU work: the whole 16-utterance batch at 3 s an utterance, four utterances of the long ones
             cb, cpu_out, cpu_batch = cpu_baseline(args.phonemes, args.frames,
@@ -525,7 +535,9 @@ def main():
         if default_line and not args.no_sub_results:
             result["sub_results"] = sub_results(net, device, overlap)
         result["range_overflow"] = net.range_overflow()
-        print(json.dumps(result), flush=True)
+        line = json.dumps(result)
+        print(f"result line: {len(line)} bytes", file=sys.stderr, flush=True)
+        print(line, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -144,8 +144,11 @@ int vits_flow_reverse(const vits_model* m, float* z, const int* frame_lengths, c
  * loops, harnesses that forbid hipMalloc): the same kernels and results, with the three work tensors in a fixed
  * 18 MiB array inside the library's device image instead of a caller workspace.  It has no counterpart in the
  * reference.  Limit: B * T <= vits_flow_noalloc_max_positions() (8192) and hidden_channels <= 192; beyond it the call
- * fails with VITS_ERR_WORKSPACE.  It calls no allocating routine.  Every call on one GPU uses that GPU's single copy
- * of the array: calls that overlap on one GPU (different streams or threads) race. */
+ * fails with VITS_ERR_WORKSPACE.  It calls no allocating routine: the array's address on a GPU is looked up by
+ * vits_model_finalize (with that GPU current; the first look-up on a device loads the device image, which allocates),
+ * so a model must have been finalized on the GPU the call runs on -- on any other GPU of the process the first call
+ * does that look-up itself and is not safe under capture.  Every call on one GPU uses that GPU's single copy of the
+ * array: calls that overlap on one GPU (different streams or threads) race. */
 int64_t vits_flow_noalloc_max_positions(void);
 int vits_flow_reverse_noalloc(const vits_model* m, float* z, const int* frame_lengths, const float* cond, int B, int T,
                               void* stream);

@@ -260,6 +260,58 @@ def test_infer_batches_equals_infer(gpu_model):
         list(gpu_model.infer_batches([dict(kws[0], bogus=1)]))
 
 
+def test_infer_batches_is_lazy(gpu_model):
+    """infer_batches takes its input as it comes: element i + 1 is asked for only after result i - 1 was handed over,
+    and a source that has nothing more for now says None, upon which the results still in the pipeline come out
+    before the source is asked again -- a serving loop that builds request i + 1 only after it has delivered result i
+    (reference inference_api.py:38-60 serves one request at a time).  Host tensors go up through pinned memory on the
+    front-end stream.  Same bytes as plain infer."""
+    bs = [synthetic.make_batch(51 + i, [10 + i, 7], [60 + 9 * i, 41]) for i in range(5)]
+    kws = [dict(phonemes=b.phonemes, phonemes_lengths=b.lengths, sid=b.sid, noise_scale=b.noise_scale,
+                duration_control=b.durations, noise=b.noise) for b in bs]
+    ref = []
+    for kw in kws:
+        k = dict(kw)
+        ref.append(gpu_model.infer(k.pop("phonemes"), k.pop("phonemes_lengths"), **k)[0].cpu())
+    consumed, asked = [], []
+
+    def strict_source():                       # hands out request i only after result i - 1 was consumed
+        for i, kw in enumerate(kws):
+            if len(consumed) < i:
+                yield None                     # "nothing right now": the pipeline must drain
+            assert len(consumed) == i, "a result was held back although the source had nothing to offer"
+            asked.append((i, len(consumed)))
+            yield kw
+
+    for g in gpu_model.infer_batches(strict_source()):
+        consumed.append(g[0].cpu())
+    assert len(consumed) == len(ref) and all(torch.equal(a, b) for a, b in zip(consumed, ref))
+
+    consumed.clear()
+    asked.clear()
+
+    def eager_source():                        # always has the next request: one element of look-ahead, no more
+        for i, kw in enumerate(kws):
+            asked.append((i, len(consumed)))
+            yield kw
+
+    for g in gpu_model.infer_batches(eager_source()):
+        consumed.append(g[0].cpu())
+    assert all(torch.equal(a, b) for a, b in zip(consumed, ref))
+    assert all(i - done <= 2 for i, done in asked), asked          # request i is taken with result i - 2 delivered
+    # the two modes share the model: plain infer calls straight after throughput mode, a host copy after each, keep to
+    # the hardware-queue budget (the generator's chains get fewer streams once the two pipeline streams exist)
+    for kw, r in zip(kws[:3], ref):
+        k = dict(kw)
+        assert torch.equal(gpu_model.infer(k.pop("phonemes"), k.pop("phonemes_lengths"), **k)[0].cpu(), r)
+    assert gpu_model._budget_generator_streams(torch.cuda.current_stream()) == 2
+    own = torch.cuda.Stream()
+    with torch.cuda.stream(own):
+        assert gpu_model._budget_generator_streams(own) == 1
+        k = dict(kws[0])
+        assert torch.equal(gpu_model.infer(k.pop("phonemes"), k.pop("phonemes_lengths"), **k)[0].cpu(), ref[0])
+
+
 def test_infer_at_the_length_limits(gpu_model, oracle_model):
     """A 2048-frame utterance (the longest row the lanes-on-keys attention kernel could hold; rows of 512 and more now
     run on the matrix-core kernel) from 400 phonemes, against the oracle; a row beyond the remaining limit of 16384

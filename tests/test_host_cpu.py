@@ -296,6 +296,14 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
             return 0
 
     monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+
+    # the parent starts its ranks from its own process image, so it must not have touched the GPU runtime: every
+    # torch.cuda entry that could initialise it is made to fail while spawn_ranks runs
+    def touched(*a, **k):
+        raise AssertionError("spawn_ranks called into torch.cuda")
+    for name in ("device_count", "is_available", "init", "set_device", "current_device", "synchronize",
+                 "get_device_properties", "mem_get_info"):
+        monkeypatch.setattr(bench.torch.cuda, name, touched)
     monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--backend", "gloo"])
     assert bench.spawn_ranks(argparse.Namespace(gpus=4, backend="gloo")) == 0
     assert len(started) == 4
@@ -305,12 +313,19 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
         assert cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--backend", "gloo"]
         assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"]) == (str(r), str(r), "4", "127.0.0.1")
         assert (stdout is None) == (r == 0)                       # rank 0 prints the JSON line
-    # more ranks than GPUs over RCCL is refused before anything starts (no GPU in this container: count is 0)
-    if torch.cuda.device_count() < 2:
-        with pytest.raises(SystemExit):
-            bench.spawn_ranks(argparse.Namespace(gpus=2, backend="nccl"))
+    started.clear()
+    assert bench.spawn_ranks(argparse.Namespace(gpus=2, backend="nccl")) == 0 and len(started) == 2
+    monkeypatch.undo()
     # a rank whose WORLD_SIZE disagrees with --gpus stops instead of printing a line with the wrong n_gpus
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "2"])
     with pytest.raises(SystemExit, match="WORLD_SIZE"):
+        bench.main()
+    # a rank with no GPU under its LOCAL_RANK says so itself (RCCL needs one GPU per rank)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit, match="needs a GPU per rank"):
         bench.main()

@@ -33,11 +33,14 @@ def test_flow_reverse_noalloc_matches_workspace_version(synthetic_sd):
         N.check(lib.vits_flow_reverse(h, z_ref.data_ptr(), lengths.data_ptr(), cond.data_ptr(), B, T, ws.data_ptr(),
                                       ws.numel(), stream), "flow_reverse")
         z_new = z0.clone()
+        torch.cuda.synchronize(dev)
         before = torch.cuda.memory_allocated(dev)
+        free_before = torch.cuda.mem_get_info(dev)[0]             # the driver's view: sees hipMalloc and image loads too
         N.check(lib.vits_flow_reverse_noalloc(h, z_new.data_ptr(), lengths.data_ptr(), cond.data_ptr(), B, T, stream),
                 "flow_reverse_noalloc")
-        assert torch.cuda.memory_allocated(dev) == before
         torch.cuda.synchronize(dev)
+        assert torch.cuda.memory_allocated(dev) == before
+        assert torch.cuda.mem_get_info(dev)[0] >= free_before     # first call included: the array was mapped at load
         assert not torch.equal(z_ref, z0)                                          # the flow did something
         assert torch.equal(z_new, z_ref)                                           # same kernels, same bytes
     # beyond the fixed array: a clear error, nothing launched
@@ -47,4 +50,6 @@ def test_flow_reverse_noalloc_matches_workspace_version(synthetic_sd):
     cond = torch.zeros(B, lib.vits_cond_rows(h), device=dev)
     rc = lib.vits_flow_reverse_noalloc(h, z.data_ptr(), lengths.data_ptr(), cond.data_ptr(), B, T, stream)
     assert rc == -4 and b"8192" in lib.vits_last_error()
+    assert lib.vits_flow_reverse_noalloc(h, None, lengths.data_ptr(), cond.data_ptr(), 1, 8, stream) != 0
+    assert b"null argument" in lib.vits_last_error()
     torch.cuda.synchronize(dev)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -120,6 +121,27 @@ __device__ __forceinline__ void ln_combine(const float* __restrict__ st, int uni
   }
   rstd = 1.f / sqrtf(m2 / (64.f * (float)units) + 1e-5f);
 }
+
+// A kernel that uses more than 64 KiB of dynamic LDS has to be given the attribute once per DEVICE (a model can be
+// moved to another GPU of the process).  One of these per kernel instantiation (a function-local static); ensure()
+// sets the attribute on the current device the first time it is called there.  Setting it twice is harmless, so a
+// relaxed flag per device is all the synchronisation concurrent callers need.
+struct LdsAttr {
+  static constexpr int kMaxDevices = 64;
+  std::atomic<bool> done[kMaxDevices];
+  LdsAttr() { for (auto& d : done) d.store(false, std::memory_order_relaxed); }
+  hipError_t ensure(const void* kernel, size_t lds) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < kMaxDevices;
+    if (tracked && done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && tracked) done[dev].store(true, std::memory_order_release);
+    return e;
+  }
+};
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
 // true when launch_conv would run this conv on the split-K kernel for a batch of B rows of L steps (the only kernel

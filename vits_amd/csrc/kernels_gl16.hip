@@ -443,13 +443,9 @@ hipError_t launch_cfg(ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 64 * WGM, BN = 32 * WN * WGN;
   constexpr size_t lds = ((size_t)S * BM * 4 + (size_t)2 * 4 * (BN + MAX_HALO)) * sizeof(uint4);
   static_assert(lds <= 80 * 1024, "two blocks to a CU");
-  static bool attr_set = false;                  // more than 64 KiB of dynamic LDS has to be asked for once per kernel
-  if (!attr_set && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gl16_kernel<WN, WGM, WGN, K, S>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsAttr attr;
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(&conv_gl16_kernel<WN, WGM, WGN, K, S>), lds); e != hipSuccess)
+    return e;
   dim3 grid((a.L + BN - 1) / BN, a.M / BM, a.B);
   char name[96];
   snprintf(name, sizeof name, "conv_gl16_kernel<%d,%d,%d,%d,%d>", WN, WGM, WGN, K, S);

@@ -555,19 +555,16 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
 }
 
 template <int NW>
-static void attention_mfma_launch(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
+static hipError_t attention_mfma_launch(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
                                   int B, int H, int L, hipStream_t s) {
   constexpr int NQ = 32 * NW;
   const size_t lds = (size_t)(3 * ATT_NCG * ATT_KT + 3 * ATT_DK * 8 + 3 * ATT_DK * 2) * sizeof(uint4) +
                      (size_t)2 * NQ * (2 * ATT_W + 1) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel<NW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static LdsAttr attr;
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attention_mfma_kernel<NW>), lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((attention_mfma_kernel<NW>), dim3((L + NQ - 1) / NQ, H, B), dim3(64 * NW), lds, s, qkv, emb_k, emb_v,
                      lengths, out, H, L);
+  return hipGetLastError();
 }
 
 // VITS_ATT_MFMA: the shortest sequence that takes the matrix-core kernel (default 256; 0 = never).
@@ -589,10 +586,8 @@ hipError_t launch_attention(const float* qkv, const float* emb_k, const float* e
   if (att_mfma_min_len() > 0 && L >= att_mfma_min_len() && (L >= 2 * att_mfma_min_len() || blocks64 >= device_cu_count())) {
     // 128 queries a block when that still gives every CU two blocks, else 64
     if ((long long)((L + 127) / 128) * H * B >= 2LL * device_cu_count())
-      attention_mfma_launch<4>(qkv, emb_k, emb_v, lengths, out, B, H, L, s);
-    else
-      attention_mfma_launch<2>(qkv, emb_k, emb_v, lengths, out, B, H, L, s);
-    return hipGetLastError();
+      return attention_mfma_launch<4>(qkv, emb_k, emb_v, lengths, out, B, H, L, s);
+    return attention_mfma_launch<2>(qkv, emb_k, emb_v, lengths, out, B, H, L, s);
   }
   if (L > 2048) return hipErrorInvalidValue;       // the lanes-on-keys kernel holds a whole score row in registers
   const int nch = (L + 63) / 64;

@@ -433,6 +433,8 @@ int vits_model_set_conv(vits_model* m, const char* name, const void* w, const fl
   return VITS_OK;
 }
 
+namespace { int flow_scratch_for_current_device(void** out); }
+
 int vits_model_finalize(vits_model* m) {
   if (!model_alive(m)) return fail(VITS_ERR_INVALID, "finalize: not a live model handle");
   const vits_config& c = m->cfg;
@@ -547,6 +549,11 @@ int vits_model_finalize(vits_model* m) {
     HIP_TRY(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
     m->n_side = i + 1;
   }
+  // vits_flow_reverse_noalloc's array: its address on this device is looked up here, at load time, because the first
+  // look-up on a device makes the runtime load this file's device image (the array included), which allocates --
+  // the entry point itself must not, and after this it only reads the pointer
+  void* scratch = nullptr;
+  TRY(flow_scratch_for_current_device(&scratch));
   m->finalized = true;
   return VITS_OK;
 }
@@ -897,6 +904,7 @@ int64_t vits_flow_noalloc_max_positions(void) { return VITS_NOALLOC_MAX_POSITION
 int vits_flow_reverse_noalloc(const vits_model* m, float* z, const int* lengths, const float* cond, int B, int T,
                               void* stream) {
   CHECK_MODEL(m);
+  if (!z || !lengths || !cond) return fail(VITS_ERR_INVALID, "flow_reverse_noalloc: null argument");
   if (B <= 0 || T <= 0) return fail(VITS_ERR_INVALID, "flow_reverse_noalloc: B and T must be positive");
   if (m->cfg.hidden_channels > VITS_NOALLOC_MAX_HIDDEN || (int64_t)B * T > VITS_NOALLOC_MAX_POSITIONS ||
       vits_flow_workspace_bytes(m, B, T) > kFlowScratchBytes)

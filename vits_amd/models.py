@@ -239,6 +239,32 @@ class SynthesizerTrn:
             return False
         return bool(int(self._range.cpu()))
 
+    # ---- hardware-queue budget ----
+    def _budget_generator_streams(self, caller) -> int:
+        """How many streams vits_generator may spread its ResBlock chains over for a call from `caller`, and tells the
+        library.  A HIP process schedules four hardware queues at once, and every stream that has carried work holds
+        one: the process's default stream, the caller's if it is another, and -- for the rest of the model's life,
+        once infer_batches has run -- its front-end and generator streams, busy or idle.  With a fifth queue in play a
+        host copy issued beside the generator's streams was seen to hang, so the chains get what the four leave over;
+        a caller on a stream of its own is taken to hold one more stream besides it."""
+        default = caller == torch.cuda.default_stream(self.device)
+        used = (1 if default else 3) + (2 if getattr(self, "_s_fe", None) is not None else 0)
+        n = 1 + max(0, min(2, 4 - used))
+        n = int(os.environ.get("VITS_INFER_GEN_STREAMS", n))
+        N.check(N.lib.vits_model_set_generator_streams(self._handle, n), "set_generator_streams")
+        return n
+
+    def _read_back(self, ints: torch.Tensor) -> torch.Tensor:
+        """Device int32 vector -> host, through the model's pinned buffer: an asynchronous copy on the current stream
+        followed by a wait for that stream (not a blocking copy to pageable memory, which waits inside the copy call
+        with a barrier packet on the queue)."""
+        n = ints.numel()
+        if getattr(self, "_pin", None) is None or self._pin.numel() < n:
+            self._pin = torch.empty(max(n, 1024), dtype=torch.int32).pin_memory()
+        self._pin[:n].copy_(ints, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._pin[:n].clone()
+
     # ---- workspace ----
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != self.device:
@@ -257,6 +283,7 @@ class SynthesizerTrn:
             fe = self._frontend(phonemes, phonemes_lengths, sid, noise_scale, max_len, energy_control, pitch_control,
                                 duration_control, noise, stages)
             B, T, t_dec = fe["B"], fe["T"], fe["t_dec"]
+            self._budget_generator_streams(torch.cuda.current_stream(dev))
             stream = torch.cuda.current_stream(dev).cuda_stream
             ws = self._workspace(N.lib.vits_generator_workspace_bytes(self._handle, B, t_dec))
             o = torch.empty(B, 1, t_dec * self.total_upsample, dtype=torch.float32, device=dev)
@@ -267,8 +294,14 @@ class SynthesizerTrn:
     @torch.no_grad()
     def infer_batches(self, batches):
         """Throughput mode for a sequence of independent batches: yields infer()'s tuple for each element of
-        `batches` (an iterable of dicts of infer()'s arguments; consumed and uploaded up front), in order, with the
-        same values infer() returns.
+        `batches` (an iterable of dicts of infer()'s arguments), in order, with the same values infer() returns.
+
+        `batches` is consumed lazily, one element ahead of the results: element i + 1 is taken only after the result
+        of element i - 1 has been handed to the consumer, so a serving loop can feed requests as they arrive (the
+        reference's server takes them one at a time, reference inference_api.py:38-60).  An element that is None
+        means "nothing more right now": the results still in the pipeline are yielded before the next element is
+        asked for.  Host tensors in an element go to the GPU through pinned memory with asynchronous copies on the
+        front-end stream; no blocking copy is issued while the streams are in flight.
 
         The front end of a batch (text encoder ... flow: many short kernels and one host round trip for the frame
         count) leaves most of the GPU idle, and the generator of the previous batch does not depend on it, so the two
@@ -279,7 +312,8 @@ class SynthesizerTrn:
         Streams: the caller's, the front-end stream, the generator stream and ONE library side stream for the
         generator's ResBlock chains -- four in all, one hardware queue each (a HIP process has four by default, and
         streams of different priority never share one).  With a fifth queue in play (two side streams) this mode was
-        seen to deadlock, so the generator is held to one side stream while it runs."""
+        seen to deadlock, so the generator is held to one side stream while it runs, and every later call on this
+        model keeps counting the two streams created here (_budget_generator_streams)."""
         dev = self.device
         if not self._busy.acquire(blocking=False):
             raise RuntimeError("vits_amd.SynthesizerTrn is not re-entrant: another call is in progress on this model")
@@ -302,19 +336,31 @@ class SynthesizerTrn:
                 gen_streams = 2 if caller == torch.cuda.default_stream(dev) else 1
                 N.check(lib.vits_model_set_generator_streams(h, int(os.environ.get("VITS_BATCHES_GEN_STREAMS", gen_streams))),
                         "set_generator_streams")
-                # Every host tensor is uploaded before the side streams start, and the loop below issues no blocking
-                # host-to-device copy of its own.
-                batches = [{k: (v.to(dev) if isinstance(v, torch.Tensor) and not v.is_cuda else v) for k, v in kw.items()}
-                           for kw in batches]
                 start = torch.cuda.Event()
                 start.record(caller)
                 self._s_fe.wait_event(start)                    # inputs prepared on the caller's stream are visible
                 self._s_gen.wait_event(start)
                 pending = None
                 for kw in batches:
+                    if kw is None:                              # the source has nothing right now: drain
+                        if pending is not None:
+                            yield self._hand_over(*pending, caller)
+                            pending = None
+                        continue
                     kw = dict(kw)
-                    args = (kw.pop("phonemes"), kw.pop("phonemes_lengths"))
+                    on_device = [v for v in kw.values() if isinstance(v, torch.Tensor) and v.is_cuda]
+                    if on_device:
+                        # made on the caller's stream, possibly after `start`: the front-end stream reads them
+                        ready = torch.cuda.Event()
+                        ready.record(caller)
+                        self._s_fe.wait_event(ready)
+                        for v in on_device:
+                            v.record_stream(self._s_fe)
                     with torch.cuda.stream(self._s_fe):
+                        for k, v in kw.items():
+                            if isinstance(v, torch.Tensor) and not v.is_cuda:
+                                kw[k] = v.pin_memory().to(dev, non_blocking=True)
+                        args = (kw.pop("phonemes"), kw.pop("phonemes_lengths"))
                         fe = self._frontend(*args, kw.pop("sid", None), kw.pop("noise_scale", 1), kw.pop("max_len", None),
                                             kw.pop("energy_control", None), kw.pop("pitch_control", None),
                                             kw.pop("duration_control", None), kw.pop("noise", None), None)
@@ -352,13 +398,13 @@ class SynthesizerTrn:
                     yield self._hand_over(*pending, caller)
         finally:
             # whatever ends the loop (exhaustion, an exception, the consumer dropping the generator): the next call on
-            # this model starts after both side streams have drained, with the default stream count restored
+            # this model starts after both side streams have drained.  The two streams stay (torch hands them out of
+            # a pool and never destroys them), so later calls budget their generator streams around them.
             if getattr(self, "_s_fe", None) is not None:
                 ev = torch.cuda.Event()
                 self._s_gen.wait_stream(self._s_fe)
                 ev.record(self._s_gen)
                 self._last_use = (self._s_gen, ev)
-            lib.vits_model_set_generator_streams(h, 8)
             self._busy.release()
 
     @staticmethod
@@ -445,6 +491,7 @@ class SynthesizerTrn:
             N.check(lib.vits_flow_reverse(h, z_hat.data_ptr(), lens.data_ptr(), conds[1].data_ptr(), B, T, ws.data_ptr(),
                                           ws.numel(), stream), "flow_reverse")
             o = torch.empty(B, 1, T * self.total_upsample, **f32)
+            self._budget_generator_streams(torch.cuda.current_stream(dev))
             N.check(lib.vits_generator(h, z_hat.data_ptr(), lens.data_ptr(), conds[1].data_ptr(), B, T, T, o.data_ptr(),
                                        ws.data_ptr(), ws.numel(), stream), "generator")
             if int(err.cpu()) & 2:
@@ -530,7 +577,7 @@ class SynthesizerTrn:
                                                   totals.data_ptr(), stream), "length_regulate_plan")
             # one device-to-host copy: frame counts, id-range errors, and the fp16-range flag that generator calls
             # before this one may have raised (synchronises the stream)
-            host = torch.cat([totals, err, self._range]).cpu()
+            host = self._read_back(torch.cat([totals, err, self._range]))
             if int(host[-2]) & 1:
                 raise IndexError("phoneme id out of range of the symbol table")
             if int(host[-2]) & 2:
@@ -628,6 +675,7 @@ class InferStream:
                 s0, e0 = max(0, s - H), min(t_dec, e + H)          # window + context; the utterance's own ends stay
                 n = e0 - s0
                 with net._exclusive():                             # the lock is free again between windows
+                    net._budget_generator_streams(torch.cuda.current_stream(dev))
                     stream = torch.cuda.current_stream(dev).cuda_stream
                     ws = net._workspace(lib.vits_generator_workspace_bytes(h, B, n))
                     lens = (fe["totals"] - s0).clamp_(min=0)       # the length mask, relative to the window start
