@@ -108,9 +108,9 @@ def pmc_traffic(kernel, workload):
 def kernel_peak_tflops(name):
     if name.startswith("conv_mfma_kernel"):
         return PEAK_FP32_MFMA_TFLOPS
-    if name.startswith(("conv_bf16_kernel", "conv_glb_bf16_kernel", "resblock_pair_bf16_kernel")):
+    if name.startswith(("conv_bf16_kernel", "conv_glb_bf16_kernel", "resblock_pair_bf16_kernel", "resblock_chain_bf16_kernel")):
         return PEAK_BF16_MFMA_TFLOPS
-    if name.startswith(("conv_f16x2_kernel", "conv_gl_", "conv_gl16_", "resblock_pair_kernel")):
+    if name.startswith(("conv_f16x2_kernel", "conv_gl_", "conv_gl16_", "resblock_pair_kernel", "resblock_chain_kernel")):
         return PEAK_F16X2_TFLOPS
     return PEAK_BF16X3_TFLOPS
 
@@ -305,6 +305,50 @@ def sub_results(net, device, overlap):
     return out
 
 
+def batch1_latencies(net, device):
+    """Medians of 20 synchronised calls: C1 (configs[0]'s utterance: 50 phonemes, 3.0 s), C5 (configs[4]: the same
+    utterance with per-phoneme F0 / energy / duration overrides), and the time to the first 32-frame window of a
+    streamed C1 call.  Measured before the throughput run creates its two pipeline streams: a latency-serving process
+    does not run infer_batches, and the generator's chains then have three streams instead of two."""
+    from vits_amd import synthetic
+    b1 = to_device(synthetic.config_c1(), device)
+    for _ in range(3):
+        step(net, b1)
+    torch.cuda.synchronize(device)
+    lat = []
+    for _ in range(20):
+        t1 = time.perf_counter()
+        step(net, b1)
+        torch.cuda.synchronize(device)
+        lat.append(time.perf_counter() - t1)
+    lat.sort()
+    c5 = synthetic.config_c5()
+    d5 = to_device(c5, device)
+    kw5 = dict(sid=d5["sid"], noise_scale=0.667, duration_control=d5["durations"], noise=d5["noise"],
+               pitch_control=c5.pitch_hz.to(device), energy_control=c5.energy.to(device))
+    lat5 = []
+    for i in range(23):
+        t1 = time.perf_counter()
+        net.infer(d5["phonemes"], d5["lengths"], **kw5)
+        torch.cuda.synchronize(device)
+        if i >= 3:
+            lat5.append(time.perf_counter() - t1)
+    lat5.sort()
+    kw1 = dict(sid=b1["sid"], noise_scale=0.667, duration_control=b1["durations"], noise=b1["noise"])
+    lat_first = []
+    for i in range(23):
+        t1 = time.perf_counter()
+        next(iter(net.infer_stream(b1["phonemes"], b1["lengths"], chunk_frames=32, **kw1)))
+        torch.cuda.synchronize(device)
+        if i >= 3:
+            lat_first.append(time.perf_counter() - t1)
+    lat_first.sort()
+    med = lat[len(lat) // 2]
+    return {"rtf_batch1": round(med / synthetic.config_c1().audio_seconds, 5), "batch1_latency_ms": round(med * 1e3, 3),
+            "batch1_edit_latency_ms": round(lat5[len(lat5) // 2] * 1e3, 3),
+            "stream_first_window_ms": round(lat_first[len(lat_first) // 2] * 1e3, 3)}
+
+
 def workload_name(args):
     shape = (args.batch, args.phonemes, args.frames)
     if shape == (16, 50, 258) and args.precision != "bf16":
@@ -434,6 +478,7 @@ def main():
         torch.cuda.synchronize(device)
 
     overlap = not args.no_overlap
+    latency = batch1_latencies(net, device) if rank == 0 and not args.no_latency else None
     run_steps(net, [d] * args.warmup, overlap)
     barrier()
     t0 = time.perf_counter()
@@ -450,44 +495,6 @@ def main():
         roofline = roofline_pass(net, lambda: step(net, d), args.steps, device,
                                  traffic_key=dict(batch=args.batch, frames=args.frames, phonemes=args.phonemes,
                                                   precision=net.precision))
-        # batch-1 latency (3.0 s utterance)
-        lat = [float("nan")]
-        if not args.no_latency:
-            b1 = to_device(synthetic.config_c1(), device)
-            for _ in range(3):
-                step(net, b1)
-            torch.cuda.synchronize(device)
-            lat = []
-            for _ in range(20):
-                t1 = time.perf_counter()
-                step(net, b1)
-                torch.cuda.synchronize(device)
-                lat.append(time.perf_counter() - t1)
-            lat.sort()
-            # configs[4]: the same utterance with per-phoneme F0 / energy / duration overrides (tensor controls)
-            c5 = synthetic.config_c5()
-            d5 = to_device(c5, device)
-            kw5 = dict(sid=d5["sid"], noise_scale=0.667, duration_control=d5["durations"], noise=d5["noise"],
-                       pitch_control=c5.pitch_hz.to(device), energy_control=c5.energy.to(device))
-            lat5 = []
-            for i in range(23):
-                t1 = time.perf_counter()
-                net.infer(d5["phonemes"], d5["lengths"], **kw5)
-                torch.cuda.synchronize(device)
-                if i >= 3:
-                    lat5.append(time.perf_counter() - t1)
-            lat5.sort()
-            # streaming: time until the first 32-frame window (0.37 s of audio) of the C1 utterance is on the device
-            kw1 = dict(sid=b1["sid"], noise_scale=0.667, duration_control=b1["durations"], noise=b1["noise"])
-            lat_first = []
-            for i in range(23):
-                t1 = time.perf_counter()
-                next(iter(net.infer_stream(b1["phonemes"], b1["lengths"], chunk_frames=32, **kw1)))
-                torch.cuda.synchronize(device)
-                if i >= 3:
-                    lat_first.append(time.perf_counter() - t1)
-            lat_first.sort()
-        rtf = lat[len(lat) // 2] / synthetic.config_c1().audio_seconds
         flops_step = algorithmic_flops([args.phonemes] * args.batch, [args.frames] * args.batch)
         arith = "bf16 generator convs" if net.precision == "bf16" else f"fp32-grade {net.precision} convs"
         result = {
@@ -513,12 +520,8 @@ def main():
             "whole_path_tflops": round(world * args.steps * flops_step / elapsed / 1e12, 2),
             "roofline": roofline,
         }
-        if not args.no_latency:
-            # BASELINE's metric has a second half, batch-1 RTF: it rides in `config` and, identically, at the top
-            # level (C1 = configs[0]'s utterance, C5 = configs[4]'s edit path; medians of 20 calls)
-            latency = {"rtf_batch1": round(rtf, 5), "batch1_latency_ms": round(lat[len(lat) // 2] * 1e3, 3),
-                       "batch1_edit_latency_ms": round(lat5[len(lat5) // 2] * 1e3, 3),
-                       "stream_first_window_ms": round(lat_first[len(lat_first) // 2] * 1e3, 3)}
+        if latency is not None:
+            # BASELINE's metric has a second half, batch-1 RTF: it rides in `config` and, identically, at the top level
             result["config"].update(latency)
             result["roofline"].update(rtf_batch1=latency["rtf_batch1"])
             result.update(latency)

@@ -429,6 +429,88 @@ def test_resblock_pair_fused_bf16(N, C, k, dil, L, B, acc):
     assert (out.cpu() - y).abs().max() < 2e-2          # a bf16 rounding of the intermediate can flip on its last bit
 
 
+def _ptr_array(tensors):
+    import ctypes as C
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+@pytest.mark.parametrize("prec,C,k,dils,L,B,acc", [
+    ("f16x2", 32, 3, (1, 3, 5), 1000, 2, False), ("f16x2", 32, 3, (1, 3, 5), 232, 1, True),
+    ("f16x2", 32, 3, (1, 3, 5), 233, 2, True), ("f16x2", 64, 3, (1, 3, 5), 700, 2, True),
+    ("f16x2", 64, 3, (1, 3, 5), 104, 1, False), ("f16x2", 32, 7, (1, 3, 5), 1500, 2, True),
+    ("f16x2", 32, 11, (1, 3, 5), 700, 1, False), ("f16x2", 64, 7, (1, 3, 5), 333, 1, False),
+    ("f16x2", 32, 3, (1, 2), 500, 2, False), ("f16x2", 32, 5, (1, 3, 5, 2), 40, 3, True),
+    ("bf16", 32, 3, (1, 3, 5), 1000, 2, True), ("bf16", 32, 7, (1, 3, 5), 1761, 2, False),
+    ("bf16", 32, 11, (1, 3, 5), 1200, 1, True), ("bf16", 64, 3, (1, 3, 5), 465, 2, True),
+    ("bf16", 64, 7, (1, 3, 5), 900, 2, False), ("bf16", 64, 11, (1, 3, 5), 300, 1, True),
+    ("bf16", 32, 7, (1, 3, 5), 440, 1, True), ("bf16", 64, 3, (5, 1, 3), 17, 2, False)])
+def test_resblock_chain_fused(N, prec, C, k, dils, L, B, acc):
+    """A whole ResBlock in one launch (the carrier of a time tile stays in registers across its pairs) against the
+    same pairs launched one after the other: the same products in the same order, so the same bytes -- across tile
+    borders (lengths on and around a tile's 232 / 104 / 184 / 440 owned steps), at both sequence ends, shorter than one
+    tile, with two, three and four pairs, and with the accumulate form used for the sum of a stage's ResBlocks; and
+    against plain fp32 math (reference modules.py:206-219)."""
+    from vits_amd import weights
+    p = PREC[prec]
+    g = torch.Generator().manual_seed(k * 100 + L + C)
+    n = len(dils)
+    ws = [(torch.randn(C, C, k, generator=g) / math.sqrt(C * k), torch.randn(C, C, k, generator=g) / math.sqrt(C * k))
+          for _ in range(n)]
+    bs = [(dev(torch.randn(C, generator=g) * 0.3), dev(torch.randn(C, generator=g) * 0.3)) for _ in range(n)]
+    pk = [(dev(weights.pack_rows(w1, p)), dev(weights.pack_rows(w2, p))) for w1, w2 in ws]
+    x = dev(torch.randn(B, C, L, generator=g))
+    init = dev(torch.randn(B, C, L, generator=g))
+    stream = torch.cuda.current_stream().cuda_stream
+    cur = x
+    for q in range(n):                                     # the pair-by-pair path: ping-pong carriers, the last one joins the sum
+        last = q + 1 == n
+        dst = init.clone() if last else torch.empty_like(x)
+        N.check(N.lib.vits_op_resblock_pair_prec(pk[q][0].data_ptr(), bs[q][0].data_ptr(), pk[q][1].data_ptr(),
+                                                 bs[q][1].data_ptr(), C, k, dils[q], p, cur.data_ptr(), dst.data_ptr(), B,
+                                                 L, 1 if (acc and last) else 0, 0.1, stream), "pair")
+        cur = dst
+    ref = cur
+    out = init.clone()
+    import ctypes as Ct
+    N.check(N.lib.vits_op_resblock_chain(_ptr_array([a for a, _ in pk]), _ptr_array([a for a, _ in bs]),
+                                         _ptr_array([b for _, b in pk]), _ptr_array([b for _, b in bs]), C, k,
+                                         (Ct.c_int * n)(*dils), n, p, x.data_ptr(), out.data_ptr(), B, L, 1 if acc else 0,
+                                         0.1, stream), "chain")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    y = x.cpu()
+    for q in range(n):
+        (w1, w2), (b1, b2) = ws[q], bs[q]
+        t = F.conv1d(rq(F.leaky_relu(y, 0.1), p), rq(w1, p), b1.cpu(), padding=(k - 1) // 2 * dils[q], dilation=dils[q])
+        y = F.conv1d(rq(F.leaky_relu(t, 0.1), p), rq(w2, p), b2.cpu(), padding=(k - 1) // 2) + y
+    if acc:
+        y = y + init.cpu()
+    assert (out.cpu() - y).abs().max() < (1e-4 if prec == "f16x2" else 5e-2)
+
+
+def test_resblock_chain_refuses_unsupported_shapes(N):
+    """One pair only (the pair kernel's job), five pairs, halos that add up to more than 64 steps a side, in-place
+    use and other channel counts are errors, never launches."""
+    import ctypes as Ct
+    from vits_amd import weights
+    p = PREC["f16x2"]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(C, k, dils, in_place=False):
+        w = torch.zeros(C, C, k)
+        pk, b = dev(weights.pack_rows(w, p)), dev(torch.zeros(C))
+        x, out = dev(torch.zeros(1, C, 64)), dev(torch.zeros(1, C, 64))
+        n = len(dils)
+        return N.lib.vits_op_resblock_chain(_ptr_array([pk] * n), _ptr_array([b] * n), _ptr_array([pk] * n),
+                                            _ptr_array([b] * n), C, k, (Ct.c_int * n)(*dils), n, p, x.data_ptr(),
+                                            (x if in_place else out).data_ptr(), 1, 64, 0, 0.1, stream)
+    assert call(32, 3, (1, 3, 5)) == 0
+    assert call(32, 3, (1,)) != 0 and call(32, 3, (1, 1, 1, 1, 1)) != 0
+    assert call(32, 11, (5, 5, 5)) != 0 and call(96, 3, (1, 3, 5)) != 0 and call(32, 4, (1, 3, 5)) != 0
+    assert call(32, 3, (1, 3, 5), in_place=True) != 0
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("C,k,dil", [(32, 13, 1), (32, 4, 1), (32, 11, 6), (96, 3, 1), (32, 1, 1)])
 def test_resblock_pair_refuses_unsupported_shapes(N, C, k, dil):
     """Tap counts without an instantiation (odd, 3..11), a first-conv halo over 25 steps and other channel counts

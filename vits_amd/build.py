@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvits_amd.so")
-SOURCES = ["kernels_conv.hip", "kernels_gl16.hip", "kernels_misc.hip", "model.hip"]
+SOURCES = ["kernels_conv.hip", "kernels_gl16.hip", "kernels_chain.hip", "kernels_misc.hip", "model.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

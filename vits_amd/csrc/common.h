@@ -164,6 +164,13 @@ bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2);       // the kernel s
 bool pair_profitable(const ConvDesc& c1, const ConvDesc& c2);    // ... and is the faster choice for it
 hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const PairArgs& a, hipStream_t stream);
 
+// A whole ResBlock -- npair pairs of the same width, tap count and arithmetic, one dilation each -- in one launch
+// (kernels_chain.hip): the carrier stays on chip across the pairs.  a.x is the ResBlock's input, a.out its output (or
+// the sum it joins, with a.accumulate); they must not overlap.
+bool chain_fusable(const ConvDesc* c1, const ConvDesc* c2, int npair);      // the kernel supports the chain
+bool chain_profitable(const ConvDesc* c1, const ConvDesc* c2, int npair);   // ... and is the faster choice for it
+hipError_t launch_resblock_chain(const ConvDesc* c1, const ConvDesc* c2, int npair, const PairArgs& a, hipStream_t stream);
+
 // Optional per-kernel timing of the conv launches with HIP events on the launch stream (off by default).
 struct ProfRow {
   std::string name;      // kernel instantiation, e.g. conv_mfma_kernel<2,2,1,4,0> = <WM,WN,WGM,WGN,MODE>

@@ -1,0 +1,401 @@
+// A whole ResBlock in one launch (gfx950, wave64): x -> x + c2(lrelu(c1(lrelu(x)))), once per dilation, with the fp32
+// carrier of a time tile kept in registers across the pairs (reference modules.py:206-219, ResBlock1.forward; its
+// output joins the stage's sum as in models.py:292-298).
+//
+// The 32- and 64-channel stages of the generator are bandwidth-bound: a ResBlock done pair by pair reads and writes its
+// carrier three times (resblock_pair_kernel), done conv by conv six times.  Here a block owns W1 consecutive time
+// steps: it reads x once, runs every pair on the tile -- the operand of each conv (leaky-relu'd, converted, zero outside
+// the sequence, as the conv's zero padding requires) goes through ONE LDS tile that the x operand and the intermediate
+// take turns in -- and writes the result once.  A tile loses (K - 1) / 2 * (dilation + 1) columns on either side per
+// pair to its neighbours' data, R in all; the block stores the inner W1 - 2 R columns and its neighbours recompute the
+// rest (12 columns a side for 3 taps, 36 for 7, 60 for 11 with dilations 1, 3, 5).
+//
+// Everything lives in the accumulator layout of v_mfma_f32_32x32x16 (lane = column l31 of an n-tile, rows
+// 8 g + 4 par + q for register 4 g + q): the carrier, the global loads and stores (runs of 32 time steps per row), and
+// the operand writes, which are 8-byte pieces -- four consecutive channels of a column, the two lane halves completing
+// a 16-byte unit.  No value changes lanes, so there is no transposition through LDS.
+//
+// Every output sees the same products in the same order as in resblock_pair_kernel and in the two-launch pair (chunk by
+// chunk, tap by tap; per tap h*l, h*h, l*h in f16x2), then + bias, + x, and for the last pair + the stage's sum: the
+// same bytes as the pair-by-pair path.
+#include "common.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace vits {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CHAIN_MAX_PAIRS = 4;
+template <int V>
+struct IntC { static constexpr int value = V; };
+
+struct ChainArgs {
+  const float* x; long long x_bs; int x_cs;
+  float* out; long long out_bs; int out_cs;
+  int B, L;
+  int accumulate;                  // out += result (read-modify-write)
+  float slope;                     // leaky-relu slope before every conv
+  int* range_flag;                 // f16x2: OR 1 into it when an in-sequence activation was clamped to the fp16 range
+  int xcd_map;
+  int npair;                       // pairs in the chain
+  int dil[CHAIN_MAX_PAIRS];        // dilation of each pair's first conv (the second conv's is 1)
+  int R;                           // columns a tile loses on each side: sum over the pairs of (K - 1) / 2 * (dil + 1)
+  int H;                           // zero columns on each side of the operand tile: (K - 1) / 2 * the largest dilation
+  const uint4* w1[CHAIN_MAX_PAIRS]; const float* b1[CHAIN_MAX_PAIRS];
+  const uint4* w2[CHAIN_MAX_PAIRS]; const float* b2[CHAIN_MAX_PAIRS];
+};
+
+// weight fragments kept in flight: a multiple that divides the 2 * NT taps of a pair, so that a tap's ring slot does
+// not depend on the pair it belongs to
+constexpr int chain_ring(int nt2, int want) {
+  int d = want;
+  while (nt2 % d) --d;
+  return d;
+}
+
+// MT = channels / 32.  NP: operand planes (2: f16x2, fp16 h / l, three products a tap; 1: plain bf16, one product).
+// WR: 32-row tiles per wave (MT / WR waves side by side in rows, the rest of the block's four side by side in time).
+// NJ: 32-column tiles per wave.  The block's tile is W1 = 32 NJ * (waves in time) steps wide.
+// BPC: blocks per CU the register budget is set for.
+template <int MT, int K, int NP, int WR, int NJ, int BPC>
+__global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArgs a) {
+  static_assert(MT % WR == 0 && 4 % (MT / WR) == 0, "whole waves in rows and in time");
+  constexpr int WGM = MT / WR, WGN = 4 / WGM, CW = 32 * NJ, W1 = CW * WGN, NCH = 2 * MT;
+  constexpr int NT = NCH * K;                               // taps per conv
+  // depth of the weight ring: what the registers of the build leave room for
+  constexpr int D = chain_ring(2 * NT, BPC >= 3 ? (MT == 2 && NP == 2 ? 3 : 4) : WR == 2 ? 7 : (NJ == 4 && NP == 2) ? 4 : 8);
+  static_assert((2 * NT) % D == 0 && D >= 2, "ring slots must line up across pairs");
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int par = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z;
+  const int BN = W1 - 2 * a.R;
+  const int t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
+  const int COLS = W1 + 2 * a.H;                            // operand tile [NCH chunks][NP planes][2 halves][COLS] of 16 bytes
+  const int c0 = wn * CW + l31;                             // this lane's column in its n-tile 0 (+ 32 j)
+  const int tl = t0 - a.R + c0;                             // ... and its time step
+  constexpr int h2 = (K - 1) / 2;
+
+  // zero columns on either side of the tile: what a conv reads beyond the tile's edge (results there are the
+  // neighbours' to compute, but they must not be garbage: they are range-checked and recirculate)
+  for (int i = tid; i < 2 * a.H * NCH * NP * 2; i += 256) {
+    const int row = i / (2 * a.H), c = i % (2 * a.H);
+    lds[row * COLS + (c < a.H ? c : W1 + c)] = make_uint4(0, 0, 0, 0);
+  }
+
+  // weight ring: tap g of the virtual sequence [first conv's NT taps, second conv's NT taps, the next pair's first
+  // taps] lives in slot g % D
+  uint4 Aq[D][WR][NP];
+  const uint4 *wa = a.w1[0], *wb = a.w2[0], *wc = a.w1[a.npair > 1 ? 1 : 0];
+  auto fetch_a = [&](int g) __attribute__((always_inline)) {
+    const uint4* base = g < NT ? wa : g < 2 * NT ? wb : wc;
+    const int tap = g < NT ? g : g < 2 * NT ? g - NT : g - 2 * NT;
+    const uint4* wk = base + ((long long)tap * MT + wm * WR) * (64 * NP) + lane;
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) Aq[g % D][i][p] = wk[64 * (i * NP + p)];
+  };
+#pragma unroll
+  for (int g = 0; g < D; ++g) fetch_a(g);
+
+  // the carrier: this wave's rows of its columns, in the accumulator layout, from one round trip to memory
+  float xr[WR][NJ][16];
+  {
+    const float* xb = a.x + (long long)b * a.x_bs;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int t = tl + 32 * j;
+      const int tc = t >= 0 && t < a.L ? t : 0;             // outside the sequence: any address; masked when used
+#pragma unroll
+      for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          xr[i][j][r] = xb[(long long)(32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)) * a.x_cs + tc];
+    }
+  }
+
+  f32x16 acc[WR][NJ];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  auto mma = [&](const uint4 (&af)[WR][NP], int pa, const uint4 (&bf)[NJ]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if constexpr (NP == 2)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][pa]),
+                                                             __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][pa]),
+                                                              __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+      }
+  };
+  // one conv over the operand tile: output column c reads tile columns c - reach + k * step
+  auto conv = [&](auto first_tap, int reach, int step) __attribute__((always_inline)) {
+    constexpr int g0 = decltype(first_tap)::value;
+    const int base = par * COLS + a.H - reach + c0;
+#pragma unroll
+    for (int chunk = 0; chunk < NCH; ++chunk)
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int g = g0 + chunk * K + k;
+        const int off = chunk * (2 * NP) * COLS + base + k * step;
+        uint4 Bh[NJ], Bl[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          Bh[j] = lds[off + j * 32];
+          if constexpr (NP == 2) Bl[j] = lds[2 * COLS + off + j * 32];
+        }
+        if constexpr (NP == 2) {
+          mma(Aq[g % D], 0, Bl);                           // h * l
+          mma(Aq[g % D], 0, Bh);                           // h * h
+          mma(Aq[g % D], NP - 1, Bh);                      // l * h
+        } else {
+          mma(Aq[g % D], 0, Bh);
+        }
+        fetch_a(g + D);
+      }
+  };
+  // One accumulator tile (row tile i of the wave, n-tile j) -> leaky-relu, (clamp, split into fp16 h / l | round to
+  // bf16), zero outside the sequence -> operand tile
+  uint2* t2 = reinterpret_cast<uint2*>(lds);
+  auto emit = [&](int i, int j, float& amax, auto&& v) __attribute__((always_inline)) {
+    const int t = tl + 32 * j;
+    const bool inside = t >= 0 && t < a.L;
+    const int col = a.H + c0 + 32 * j;
+    const int rt = wm * WR + i;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint2 oh, ol;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x2 e;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float x = v(4 * g + 2 * u + q);
+          x = fmaxf(x, x * a.slope);
+          if constexpr (NP == 2) {
+            if (inside) amax = fmaxf(amax, fabsf(x));
+            x = fminf(fmaxf(x, -65504.f), 65504.f);
+          }
+          e[q] = inside ? x : 0.f;
+        }
+        if constexpr (NP == 2) {
+          const f16x2 h = __builtin_convertvector(e, f16x2);
+          const f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, f32x2), f16x2);
+          (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, h);
+          (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, l);
+        } else {
+          (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2));
+        }
+      }
+      const int chunk = 2 * rt + (g >> 1), half = g & 1;
+      t2[(((chunk * NP + 0) * 2 + half) * COLS + col) * 2 + par] = oh;
+      if constexpr (NP == 2) t2[(((chunk * NP + 1) * 2 + half) * COLS + col) * 2 + par] = ol;
+    }
+  };
+
+  auto report = [&](float amax) __attribute__((always_inline)) {
+    if constexpr (NP == 2) {
+      if (a.range_flag && !(amax <= 65504.f)) atomicOr(a.range_flag, 1);
+    }
+  };
+  for (int p = 0; p < a.npair; ++p) {
+    const int dil = a.dil[p];
+    const float* b1 = a.b1[p];
+    const float* b2 = a.b2[p];
+    if (p > 0) {
+      wa = a.w1[p];
+      wb = a.w2[p];
+      wc = a.w1[p + 1 < a.npair ? p + 1 : p];               // the last pair's look-ahead lands on valid memory, unused
+      __syncthreads();                                      // every wave has read its last fragment of the previous pair
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) emit(i, j, amax, [&](int r) { return xr[i][j][r]; });
+    report(amax);
+    __syncthreads();
+    zero_acc();
+    conv(IntC<0>{}, h2 * dil, dil);
+    __syncthreads();                                        // every wave has read the x operand
+    amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      float bz[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bz[r] = b1 ? b1[32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) emit(i, j, amax, [&](int r) { return acc[i][j][r] + bz[r]; });
+    }
+    report(amax);
+    __syncthreads();
+    zero_acc();
+    conv(IntC<NT>{}, h2, 1);
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      float bz[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bz[r] = b2 ? b2[32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float y = acc[i][j][r] + bz[r];             // c2 + bias, then + x: the order of the pair kernels
+          xr[i][j][r] = y + xr[i][j][r];
+        }
+    }
+  }
+
+  // ---- out = carrier (+ out) on the columns this block owns ----
+  {
+    float* ob = a.out + (long long)b * a.out_bs;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = c0 + 32 * j, t = tl + 32 * j;
+      const bool mine = c >= a.R && c < W1 - a.R && t < a.L;
+      const int tc = mine ? t : 0;
+      if (a.accumulate) {                                   // all loads of the n-tile before its first store
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] = ob[(long long)(32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)) * a.out_cs + tc];
+      }
+      if (mine) {
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = xr[i][j][r];
+            if (a.accumulate) v += acc[i][j][r];
+            ob[(long long)(32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)) * a.out_cs + t] = v;
+          }
+      }
+    }
+  }
+}
+
+// Which ResBlocks take the whole-chain kernel.  VITS_CHAIN_F16X2 / VITS_CHAIN_BF16: lists of "<channels>x<taps>"
+// (measurement knobs; "none" for the pair-by-pair path everywhere).
+bool listed(const char* env, const char* dflt, int C, int K) {
+  const char* e = getenv(env);
+  const std::string v = std::string(",") + (e ? e : dflt) + ",";
+  return v.find("," + std::to_string(C) + "x" + std::to_string(K) + ",") != std::string::npos;
+}
+
+}  // namespace
+
+static int chain_radius(const ConvDesc* c1, int npair) {
+  int R = 0;
+  for (int p = 0; p < npair; ++p) R += (c1[p].K - 1) / 2 * (c1[p].tstep[0] + 1);
+  return R;
+}
+
+bool chain_fusable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
+  if (npair < 2 || npair > CHAIN_MAX_PAIRS) return false;
+  for (int p = 0; p < npair; ++p) {
+    if (!pair_fusable(c1[p], c2[p])) return false;
+    if (c1[p].M != c1[0].M || c1[p].K != c1[0].K || c1[p].prec != c1[0].prec) return false;
+  }
+  return chain_radius(c1, npair) <= 64;                     // a 256-step tile keeps at least half of its columns
+}
+
+bool chain_profitable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
+  if (!chain_fusable(c1, c2, npair)) return false;
+  const int C = c1[0].M, K = c1[0].K;
+  return c1[0].prec == PREC_BF16 ? listed("VITS_CHAIN_BF16", "32x3,64x3,32x7,32x11", C, K)
+                                 : listed("VITS_CHAIN_F16X2", "32x3,64x3", C, K);
+}
+
+hipError_t launch_resblock_chain(const ConvDesc* c1, const ConvDesc* c2, int npair, const PairArgs& pa, hipStream_t stream) {
+  if (!chain_fusable(c1, c2, npair) || pa.B <= 0 || pa.L <= 0 || pa.B > 65535) return hipErrorInvalidValue;
+  const int K = c1[0].K, MT = c1[0].M / 32, NP = c1[0].prec == PREC_BF16 ? 1 : 2, nch = 2 * MT;
+  ChainArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = pa.x; a.x_bs = pa.x_bs; a.x_cs = pa.x_cs;
+  a.out = pa.out; a.out_bs = pa.out_bs; a.out_cs = pa.out_cs;
+  a.B = pa.B; a.L = pa.L; a.accumulate = pa.accumulate; a.slope = pa.slope; a.range_flag = pa.range_flag;
+  a.xcd_map = xcd_map_enabled();
+  a.npair = npair;
+  int dmax = 1;
+  for (int p = 0; p < npair; ++p) {
+    a.dil[p] = c1[p].tstep[0];
+    dmax = std::max(dmax, a.dil[p]);
+    a.w1[p] = reinterpret_cast<const uint4*>(c1[p].w); a.b1[p] = c1[p].bias;
+    a.w2[p] = reinterpret_cast<const uint4*>(c2[p].w); a.b2[p] = c2[p].bias;
+  }
+  a.R = chain_radius(c1, npair);
+  a.H = (K - 1) / 2 * dmax;
+  // tile width: 256 steps; 512 (32 channels in one plane) where the lost columns would otherwise be over a quarter
+  static const int wide_from = getenv("VITS_CHAIN_WIDE_R") ? atoi(getenv("VITS_CHAIN_WIDE_R")) : 30;
+  const bool wide = MT == 1 && NP == 1 && a.R >= wide_from;
+  // 64 channels in two planes: 128-step tiles at three blocks to a CU, or 256-step tiles at two (VITS_CHAIN_64_WIDE)
+  static const bool wide64 = getenv("VITS_CHAIN_64_WIDE") ? atoi(getenv("VITS_CHAIN_64_WIDE")) != 0 : false;
+  const int W1 = wide ? 512 : (MT == 2 && NP == 2 && !wide64) ? 128 : 256;
+  const int BN = W1 - 2 * a.R;
+  if (BN < 32) return hipErrorInvalidValue;
+  const size_t lds = (size_t)nch * NP * 2 * (W1 + 2 * a.H) * sizeof(uint4);
+  dim3 grid((a.L + BN - 1) / BN, 1, a.B);
+  ConvArgs ta;
+  memset(&ta, 0, sizeof ta);
+  ta.M = c1[0].M; ta.Cin = c1[0].M; ta.K = 2 * npair * K; ta.L = a.L; ta.B = a.B;    // timing row: every conv's FLOPs
+  ta.flags = a.accumulate ? F_ACCUM : 0;                    // bytes: x once, the result once, the sum when accumulated
+  char name[64];
+  snprintf(name, sizeof name, NP == 1 ? "resblock_chain_bf16_kernel<%d,%d>" : "resblock_chain_kernel<%d,%d>", MT, K);
+  const ProfTicket tk = prof_begin(stream);
+  bool launched = true;
+#define CHAIN_GO(MT_, K_, NP_, WR_, NJ_, BPC_)                                                                     \
+  do {                                                                                                              \
+    static LdsAttr attr;                                                                                            \
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(&resblock_chain_kernel<MT_, K_, NP_, WR_, NJ_, BPC_>), lds); \
+        e != hipSuccess)                                                                                            \
+      return e;                                                                                                     \
+    hipLaunchKernelGGL((resblock_chain_kernel<MT_, K_, NP_, WR_, NJ_, BPC_>), grid, dim3(256), lds, stream, a);     \
+  } while (0)
+#define CHAIN_TAPS(MT_, NP_, WR_, NJ_, BPC_)                       \
+  switch (K) {                                                     \
+    case 3: CHAIN_GO(MT_, 3, NP_, WR_, NJ_, BPC_); break;          \
+    case 5: CHAIN_GO(MT_, 5, NP_, WR_, NJ_, BPC_); break;          \
+    case 7: CHAIN_GO(MT_, 7, NP_, WR_, NJ_, BPC_); break;          \
+    case 9: CHAIN_GO(MT_, 9, NP_, WR_, NJ_, BPC_); break;          \
+    case 11: CHAIN_GO(MT_, 11, NP_, WR_, NJ_, BPC_); break;        \
+    default: launched = false;                                     \
+  }
+  if (MT == 1 && NP == 2 && K > 5) { CHAIN_TAPS(1, 2, 1, 2, 2) }   // (the long tap loops do not fit three blocks' registers)
+  else if (MT == 1 && NP == 2) { CHAIN_TAPS(1, 2, 1, 2, 3) }       // 32 channels, f16x2: 256-step tile, three blocks to a CU
+  else if (MT == 1 && wide) { CHAIN_TAPS(1, 1, 1, 4, 2) }          // 32 channels, bf16: 512-step tile
+  else if (MT == 1) { CHAIN_TAPS(1, 1, 1, 2, 3) }                  // 32 channels, bf16: 256-step tile
+  else if (NP == 2 && wide64) { CHAIN_TAPS(2, 2, 1, 4, 2) }
+  else if (NP == 2 && K > 3) { CHAIN_TAPS(2, 2, 1, 2, 2) }
+  else if (NP == 2) { CHAIN_TAPS(2, 2, 1, 2, 3) }                  // 64 channels, f16x2: 128-step tile
+  else { CHAIN_TAPS(2, 1, 2, 2, 2) }                               // 64 channels, bf16: every wave all 64 rows, 256 steps
+#undef CHAIN_TAPS
+#undef CHAIN_GO
+  const hipError_t err = launched ? hipGetLastError() : hipErrorInvalidValue;
+  prof_end(tk, name, false, ta, stream);
+  return err;
+}
+
+}  // namespace vits

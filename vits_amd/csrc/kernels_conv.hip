@@ -1880,7 +1880,7 @@ void prof_end(const ProfTicket& t, const char* name, bool gate, const ConvArgs& 
   const bool plain_bf16 = strstr(name, "conv_bf16_kernel") || strstr(name, "conv_glb_bf16");
   const double wbytes = plain_bf16 ? 2.0
                         : strstr(name, "conv_mfma") || strstr(name, "conv_f16x2") || strstr(name, "conv_gl") ||
-                                strstr(name, "resblock_pair") ? 4.0 : 6.0;
+                                strstr(name, "resblock_pair") || strstr(name, "resblock_chain") ? 4.0 : 6.0;
   const double sb = plain_bf16 ? 2.0 : 4.0;                                   // bytes per staged element
   const double in_b = (a.flags & F_IN_STAGED) ? sb : 4.0, out_b = (a.flags & F_OUT_STAGED) ? sb : 4.0;
   c.bytes += (double)a.L * a.B * (in_b * a.Cin + outs * (out_b + 4.0 * reads + (a.out2 ? sb : 0.0))) + wbytes * a.M * a.Cin * a.K;

@@ -982,6 +982,15 @@ static bool fused_pairs_enabled() {
   return on;
 }
 
+// VITS_GEN_CHAIN=0 keeps every ResBlock pair by pair (measurement knob).
+static bool whole_resblocks_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_GEN_CHAIN");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec) {
   if (!model_alive(m)) return -1;
   // x, the sum of the chains, x in staged form; per ResBlock chain: its carrier, the tensor between the two convs of
@@ -1068,6 +1077,18 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
       // T before reading it.  So a chain is fused only when every one of its pairs is.
       bool fuse_chain = fused_pairs_enabled() && !single;
       for (int q = 0; q < nd && fuse_chain; ++q) fuse_chain = pair_profitable(rb.c1[q], rb.c2[q]);
+      if (whole_resblocks_enabled() && !single && chain_profitable(rb.c1.data(), rb.c2.data(), nd)) {
+        // the whole ResBlock in one launch: x is read once, the chain's result goes straight into the stage's sum
+        if (j > 0 && n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
+        PairArgs pa;
+        pa.x = X; pa.x_bs = (long long)rb.c1[0].Cin * L; pa.x_cs = L;
+        pa.out = XS; pa.out_bs = (long long)rb.c1[0].Cin * L; pa.out_cs = L;
+        pa.B = B; pa.L = L; pa.accumulate = j > 0; pa.slope = 0.1f;
+        pa.range_flag = g_range_flag;
+        HIP_TRY(launch_resblock_chain(rb.c1.data(), rb.c2.data(), nd, pa, sj));
+        if (n_side > 0) HIP_TRY(hipEventRecord(m->ev_done[j], sj));
+        continue;
+      }
       for (int q = 0; q < nd; ++q) {
         if (single) {
           // x = c(leaky_relu(x)) + x per dilation; the carrier alternates between Y and T because a conv with a halo
@@ -1182,6 +1203,31 @@ int vits_op_resblock_pair_prec(const void* w1, const float* b1, const void* w2, 
   pa.B = B; pa.L = L; pa.accumulate = accumulate; pa.slope = slope;
   pa.range_flag = g_range_flag;
   HIP_TRY(launch_resblock_pair(c1, c2, pa, (hipStream_t)stream));
+  return VITS_OK;
+}
+
+int vits_op_resblock_chain(const void* const* w1, const float* const* b1, const void* const* w2, const float* const* b2,
+                           int channels, int taps, const int* dilations, int npair, int precision, const float* x,
+                           float* out, int B, int L, int accumulate, float slope, void* stream) {
+  if (precision != PREC_F16X2 && precision != PREC_BF16)
+    return fail(VITS_ERR_INVALID, "resblock chain: precision must be f16x2 (3) or bf16 (2)");
+  if (!w1 || !w2 || !dilations || !x || !out || npair < 1 || npair > 4)
+    return fail(VITS_ERR_INVALID, "resblock chain: null argument or more than 4 pairs");
+  ConvDesc c1[4], c2[4];
+  for (int p = 0; p < npair; ++p) {
+    TRY(make_desc(c1[p], w1[p], b1 ? b1[p] : nullptr, channels, channels, taps, dilations[p], MODE_PLAIN, precision));
+    TRY(make_desc(c2[p], w2[p], b2 ? b2[p] : nullptr, channels, channels, taps, 1, MODE_PLAIN, precision));
+  }
+  if (!chain_fusable(c1, c2, npair))
+    return fail(VITS_ERR_INVALID, "resblock chain: 2 to 4 pairs of 32 or 64 channels and 3 / 5 / 7 / 9 / 11 taps whose "
+                                  "halos add up to at most 64 steps a side required");
+  if (x == out) return fail(VITS_ERR_INVALID, "resblock chain: cannot run in place");
+  PairArgs pa;
+  pa.x = x; pa.x_bs = (long long)channels * L; pa.x_cs = L;
+  pa.out = out; pa.out_bs = (long long)channels * L; pa.out_cs = L;
+  pa.B = B; pa.L = L; pa.accumulate = accumulate; pa.slope = slope;
+  pa.range_flag = g_range_flag;
+  HIP_TRY(launch_resblock_chain(c1, c2, npair, pa, (hipStream_t)stream));
   return VITS_OK;
 }
 
