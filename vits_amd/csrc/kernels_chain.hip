@@ -36,6 +36,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// Measurement builds (tools/build_variant.sh): -DCHAIN_KO=<bits> removes a part of the kernel to see what the rest
+// costs -- 1: no MFMAs, 2: no weight loads inside the tap loops, 4: operand tiles written without the conversion
+// arithmetic, 8: no fragment reads from LDS.  Results are wrong in such a build; the default build has none of it.
+#ifndef CHAIN_KO
+#define CHAIN_KO 0
+#endif
 constexpr int CHAIN_MAX_PAIRS = 4;
 template <int V>
 struct IntC { static constexpr int value = V; };
@@ -67,14 +73,19 @@ constexpr int chain_ring(int nt2, int want) {
 // MT = channels / 32.  NP: operand planes (2: f16x2, fp16 h / l, three products a tap; 1: plain bf16, one product).
 // WR: 32-row tiles per wave (MT / WR waves side by side in rows, the rest of the block's four side by side in time).
 // NJ: 32-column tiles per wave.  The block's tile is W1 = 32 NJ * (waves in time) steps wide.
-// BPC: blocks per CU the register budget is set for.
-template <int MT, int K, int NP, int WR, int NJ, int BPC>
-__global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArgs a) {
-  static_assert(MT % WR == 0 && 4 % (MT / WR) == 0, "whole waves in rows and in time");
-  constexpr int WGM = MT / WR, WGN = 4 / WGM, CW = 32 * NJ, W1 = CW * WGN, NCH = 2 * MT;
+// NW: waves per block.  With one wave (32 channels: the wave holds every channel of its columns) a block synchronises
+// with nobody, and the waves of a SIMD drift apart: one converts operands while another multiplies.
+// BPC: waves per SIMD the register budget is set for.
+template <int MT, int K, int NP, int WR, int NJ, int BPC, int NW = 4>
+__global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const ChainArgs a) {
+  static_assert(MT % WR == 0 && NW % (MT / WR) == 0, "whole waves in rows and in time");
+  constexpr int WGM = MT / WR, WGN = NW / WGM, CW = 32 * NJ, W1 = CW * WGN, NCH = 2 * MT;
   constexpr int NT = NCH * K;                               // taps per conv
   // depth of the weight ring: what the registers of the build leave room for
-  constexpr int D = chain_ring(2 * NT, BPC >= 3 ? (MT == 2 && NP == 2 ? 3 : 4) : WR == 2 ? 7 : (NJ == 4 && NP == 2) ? 4 : 8);
+#ifndef CHAIN_RING3
+#define CHAIN_RING3 4
+#endif
+  constexpr int D = chain_ring(2 * NT, BPC >= 3 ? (NP == 2 ? CHAIN_RING3 : 4) : WR == 2 ? 6 : (NJ == 4 && NP == 2) ? 3 : 8);
   static_assert((2 * NT) % D == 0 && D >= 2, "ring slots must line up across pairs");
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -89,9 +100,17 @@ __global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArg
   const int tl = t0 - a.R + c0;                             // ... and its time step
   constexpr int h2 = (K - 1) / 2;
 
+  // every conv's bias goes to LDS once (behind the operand tile: [pair][conv][32 MT] floats); read back in the
+  // accumulator layout, four consecutive rows a read
+  float* bias_lds = reinterpret_cast<float*>(lds + NCH * NP * 2 * COLS);
+  for (int i = tid; i < a.npair * 2 * 32 * MT; i += 64 * NW) {
+    const int pc = i / (32 * MT), row = i % (32 * MT);
+    const float* bp = (pc & 1) ? a.b2[pc >> 1] : a.b1[pc >> 1];
+    bias_lds[i] = bp ? bp[row] : 0.f;
+  }
   // zero columns on either side of the tile: what a conv reads beyond the tile's edge (results there are the
   // neighbours' to compute, but they must not be garbage: they are range-checked and recirculate)
-  for (int i = tid; i < 2 * a.H * NCH * NP * 2; i += 256) {
+  for (int i = tid; i < 2 * a.H * NCH * NP * 2; i += 64 * NW) {
     const int row = i / (2 * a.H), c = i % (2 * a.H);
     lds[row * COLS + (c < a.H ? c : W1 + c)] = make_uint4(0, 0, 0, 0);
   }
@@ -100,14 +119,17 @@ __global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArg
   // taps] lives in slot g % D
   uint4 Aq[D][WR][NP];
   const uint4 *wa = a.w1[0], *wb = a.w2[0], *wc = a.w1[a.npair > 1 ? 1 : 0];
+  // (a wave-uniform base per tap plus one 32-bit lane offset: the addresses live in scalar registers)
+  const unsigned lane_bytes = lane * 16u;
   auto fetch_a = [&](int g) __attribute__((always_inline)) {
     const uint4* base = g < NT ? wa : g < 2 * NT ? wb : wc;
     const int tap = g < NT ? g : g < 2 * NT ? g - NT : g - 2 * NT;
-    const uint4* wk = base + ((long long)tap * MT + wm * WR) * (64 * NP) + lane;
+    const char* wk = reinterpret_cast<const char*>(base + ((long long)tap * MT + wm * WR) * (64 * NP));
 #pragma unroll
     for (int i = 0; i < WR; ++i)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) Aq[g % D][i][p] = wk[64 * (i * NP + p)];
+      for (int p = 0; p < NP; ++p)
+        Aq[g % D][i][p] = *reinterpret_cast<const uint4*>(wk + 1024 * (i * NP + p) + lane_bytes);
   };
 #pragma unroll
   for (int g = 0; g < D; ++g) fetch_a(g);
@@ -119,12 +141,15 @@ __global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArg
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int t = tl + 32 * j;
-      const int tc = t >= 0 && t < a.L ? t : 0;             // outside the sequence: any address; masked when used
+      const bool ok = t >= 0 && t < a.L;                    // outside the sequence the carrier starts at zero and is
+      const int tc = ok ? t : 0;                            // never used: operands are zeroed there, nothing is stored
 #pragma unroll
       for (int i = 0; i < WR; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          xr[i][j][r] = xb[(long long)(32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)) * a.x_cs + tc];
+        for (int r = 0; r < 16; ++r) {
+          const float v = xb[(long long)(32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)) * a.x_cs + tc];
+          xr[i][j][r] = ok ? v : 0.f;
+        }
     }
   }
 
@@ -142,7 +167,9 @@ __global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArg
     for (int i = 0; i < WR; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        if constexpr (NP == 2)
+        if constexpr (CHAIN_KO & 1) {
+          acc[i][j][0] += __builtin_bit_cast(float, af[i][pa].x ^ bf[j].x);
+        } else if constexpr (NP == 2)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][pa]),
                                                              __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
         else
@@ -151,20 +178,36 @@ __global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArg
       }
   };
   // one conv over the operand tile: output column c reads tile columns c - reach + k * step
-  auto conv = [&](auto first_tap, int reach, int step) __attribute__((always_inline)) {
+  // LDS addresses: one vector register per conv (the lane's column and half, made opaque so that nothing derived from
+  // it is computed ahead and kept), plus per tap a wave-uniform offset -- chunk, and for the dilated conv tap * stride,
+  // a run-time value made opaque at every tap -- added where the tap is read; n-tile, and for the undilated conv the
+  // tap, sit in the instruction's offset field.  Left to itself the compiler keeps an address register per tap, plane
+  // and half alive across the whole loop over the pairs (2 to 4 K of them) and spills the carrier to make room.
+  auto conv = [&](auto first_tap, auto dilated, int reach, int step) __attribute__((always_inline)) {
     constexpr int g0 = decltype(first_tap)::value;
-    const int base = par * COLS + a.H - reach + c0;
+    int base = par * COLS + a.H - reach + c0;
+    asm volatile("" : "+v"(base));
 #pragma unroll
     for (int chunk = 0; chunk < NCH; ++chunk)
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int g = g0 + chunk * K + k;
-        const int off = chunk * (2 * NP) * COLS + base + k * step;
+        int uni = chunk * (2 * NP) * COLS;
+        if constexpr (decltype(dilated)::value != 0) {
+          uni += k * step;
+          asm volatile("" : "+s"(uni));
+        }
+        const int off = base + uni + (decltype(dilated)::value != 0 ? 0 : k);
         uint4 Bh[NJ], Bl[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          Bh[j] = lds[off + j * 32];
-          if constexpr (NP == 2) Bl[j] = lds[2 * COLS + off + j * 32];
+          if constexpr (CHAIN_KO & 8) {
+            Bh[j] = make_uint4(off, j, k, chunk);
+            Bl[j] = make_uint4(j, off, chunk, k);
+          } else {
+            Bh[j] = lds[off + j * 32];
+            if constexpr (NP == 2) Bl[j] = lds[2 * COLS + off + j * 32];
+          }
         }
         if constexpr (NP == 2) {
           mma(Aq[g % D], 0, Bl);                           // h * l
@@ -173,15 +216,22 @@ __global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArg
         } else {
           mma(Aq[g % D], 0, Bh);
         }
-        fetch_a(g + D);
+        if constexpr (!(CHAIN_KO & 2)) fetch_a(g + D);
+#ifdef CHAIN_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
   };
   // One accumulator tile (row tile i of the wave, n-tile j) -> leaky-relu, (clamp, split into fp16 h / l | round to
   // bf16), zero outside the sequence -> operand tile
   uint2* t2 = reinterpret_cast<uint2*>(lds);
+  // A conv's operand is zero outside the sequence (its zero padding): 1 or 0 per column, multiplied in before the
+  // leaky-relu (exact for the columns that stay; two packed multiplies and a max per pair of values in all)
+  float inside[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) inside[j] = (tl + 32 * j >= 0 && tl + 32 * j < a.L) ? 1.f : 0.f;
   auto emit = [&](int i, int j, float& amax, auto&& v) __attribute__((always_inline)) {
-    const int t = tl + 32 * j;
-    const bool inside = t >= 0 && t < a.L;
+    const f32x2 keep = {inside[j], inside[j]}, slope2 = {a.slope, a.slope};
     const int col = a.H + c0 + 32 * j;
     const int rt = wm * WR + i;
 #pragma unroll
@@ -189,18 +239,23 @@ __global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArg
       uint2 oh, ol;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        f32x2 e;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float x = v(4 * g + 2 * u + q);
-          x = fmaxf(x, x * a.slope);
+        f32x2 e = {v(4 * g + 2 * u), v(4 * g + 2 * u + 1)};
+        if constexpr (CHAIN_KO & 4) {
+          (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, e[0]);
+          (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, e[1]);
+        } else {
+          e = e * keep;
+          const f32x2 es = e * slope2;
+          e[0] = fmaxf(e[0], es[0]);
+          e[1] = fmaxf(e[1], es[1]);
           if constexpr (NP == 2) {
-            if (inside) amax = fmaxf(amax, fabsf(x));
-            x = fminf(fmaxf(x, -65504.f), 65504.f);
+            amax = fmaxf(amax, fmaxf(fabsf(e[0]), fabsf(e[1])));
+            e[0] = __builtin_amdgcn_fmed3f(e[0], -65504.f, 65504.f);
+            e[1] = __builtin_amdgcn_fmed3f(e[1], -65504.f, 65504.f);
           }
-          e[q] = inside ? x : 0.f;
         }
-        if constexpr (NP == 2) {
+        if constexpr (CHAIN_KO & 4) {
+        } else if constexpr (NP == 2) {
           const f16x2 h = __builtin_convertvector(e, f16x2);
           const f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, f32x2), f16x2);
           (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, h);
@@ -212,9 +267,19 @@ __global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArg
       const int chunk = 2 * rt + (g >> 1), half = g & 1;
       t2[(((chunk * NP + 0) * 2 + half) * COLS + col) * 2 + par] = oh;
       if constexpr (NP == 2) t2[(((chunk * NP + 1) * 2 + half) * COLS + col) * 2 + par] = ol;
+#ifdef CHAIN_SCHED_BARRIER2
+      __builtin_amdgcn_sched_barrier(0);       // four values at a time: the conversion's temporaries stay few
+#endif
     }
   };
 
+  auto load_bias = [&](const float4* bias, int i, float (&bz)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = bias[8 * (wm * WR + i) + 2 * g + par];      // rows 32 rt + 8 g + 4 par .. + 3
+      bz[4 * g] = v.x; bz[4 * g + 1] = v.y; bz[4 * g + 2] = v.z; bz[4 * g + 3] = v.w;
+    }
+  };
   auto report = [&](float amax) __attribute__((always_inline)) {
     if constexpr (NP == 2) {
       if (a.range_flag && !(amax <= 65504.f)) atomicOr(a.range_flag, 1);
@@ -222,8 +287,8 @@ __global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArg
   };
   for (int p = 0; p < a.npair; ++p) {
     const int dil = a.dil[p];
-    const float* b1 = a.b1[p];
-    const float* b2 = a.b2[p];
+    const float4* bias1 = reinterpret_cast<const float4*>(bias_lds + (2 * p) * 32 * MT);
+    const float4* bias2 = reinterpret_cast<const float4*>(bias_lds + (2 * p + 1) * 32 * MT);
     if (p > 0) {
       wa = a.w1[p];
       wb = a.w2[p];
@@ -238,26 +303,24 @@ __global__ __launch_bounds__(256, BPC) void resblock_chain_kernel(const ChainArg
     report(amax);
     __syncthreads();
     zero_acc();
-    conv(IntC<0>{}, h2 * dil, dil);
+    conv(IntC<0>{}, IntC<1>{}, h2 * dil, dil);
     __syncthreads();                                        // every wave has read the x operand
     amax = 0.f;
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
       float bz[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bz[r] = b1 ? b1[32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+      load_bias(bias1, i, bz);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) emit(i, j, amax, [&](int r) { return acc[i][j][r] + bz[r]; });
     }
     report(amax);
     __syncthreads();
     zero_acc();
-    conv(IntC<NT>{}, h2, 1);
+    conv(IntC<NT>{}, IntC<0>{}, h2, 1);
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
       float bz[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bz[r] = b2 ? b2[32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)] : 0.f;
+      load_bias(bias2, i, bz);
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -325,13 +388,50 @@ bool chain_fusable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
 bool chain_profitable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
   if (!chain_fusable(c1, c2, npair)) return false;
   const int C = c1[0].M, K = c1[0].K;
-  return c1[0].prec == PREC_BF16 ? listed("VITS_CHAIN_BF16", "32x3,64x3,32x7,32x11", C, K)
+  return c1[0].prec == PREC_BF16 ? listed("VITS_CHAIN_BF16", "32x3,64x3,32x7,64x7,32x11", C, K)
                                  : listed("VITS_CHAIN_F16X2", "32x3,64x3", C, K);
 }
 
+namespace {
+template <int MT, int K, int NP, int WR, int NJ, int BPC, int NW>
+hipError_t launch_build(ChainArgs& a, const char* name, const ConvArgs& ta, hipStream_t stream) {
+  constexpr int W1 = 32 * NJ * (NW / (MT / WR));
+  const int BN = W1 - 2 * a.R;
+  if (BN < 32) return hipErrorInvalidValue;
+  const size_t lds = (size_t)2 * MT * NP * 2 * (W1 + 2 * a.H) * sizeof(uint4) + (size_t)a.npair * 2 * 32 * MT * sizeof(float);
+  static LdsAttr attr;
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(&resblock_chain_kernel<MT, K, NP, WR, NJ, BPC, NW>), lds);
+      e != hipSuccess)
+    return e;
+  dim3 grid((a.L + BN - 1) / BN, 1, a.B);
+  const ProfTicket tk = prof_begin(stream);
+  hipLaunchKernelGGL((resblock_chain_kernel<MT, K, NP, WR, NJ, BPC, NW>), grid, dim3(64 * NW), lds, stream, a);
+  const hipError_t err = hipGetLastError();
+  prof_end(tk, name, false, ta, stream);
+  return err;
+}
+
+template <int MT, int NP, int WR, int NJ, int BPC, int NW>
+hipError_t launch_taps(int K, ChainArgs& a, const char* name, const ConvArgs& ta, hipStream_t stream) {
+  switch (K) {
+    case 3: return launch_build<MT, 3, NP, WR, NJ, BPC, NW>(a, name, ta, stream);
+    case 5: return launch_build<MT, 5, NP, WR, NJ, BPC, NW>(a, name, ta, stream);
+    case 7: return launch_build<MT, 7, NP, WR, NJ, BPC, NW>(a, name, ta, stream);
+    case 9: return launch_build<MT, 9, NP, WR, NJ, BPC, NW>(a, name, ta, stream);
+    case 11: return launch_build<MT, 11, NP, WR, NJ, BPC, NW>(a, name, ta, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && e[0] ? atoi(e) : dflt;
+}
+}  // namespace
+
 hipError_t launch_resblock_chain(const ConvDesc* c1, const ConvDesc* c2, int npair, const PairArgs& pa, hipStream_t stream) {
   if (!chain_fusable(c1, c2, npair) || pa.B <= 0 || pa.L <= 0 || pa.B > 65535) return hipErrorInvalidValue;
-  const int K = c1[0].K, MT = c1[0].M / 32, NP = c1[0].prec == PREC_BF16 ? 1 : 2, nch = 2 * MT;
+  const int K = c1[0].K, MT = c1[0].M / 32, NP = c1[0].prec == PREC_BF16 ? 1 : 2;
   ChainArgs a;
   memset(&a, 0, sizeof a);
   a.x = pa.x; a.x_bs = pa.x_bs; a.x_cs = pa.x_cs;
@@ -348,54 +448,36 @@ hipError_t launch_resblock_chain(const ConvDesc* c1, const ConvDesc* c2, int npa
   }
   a.R = chain_radius(c1, npair);
   a.H = (K - 1) / 2 * dmax;
-  // tile width: 256 steps; 512 (32 channels in one plane) where the lost columns would otherwise be over a quarter
-  static const int wide_from = getenv("VITS_CHAIN_WIDE_R") ? atoi(getenv("VITS_CHAIN_WIDE_R")) : 30;
-  const bool wide = MT == 1 && NP == 1 && a.R >= wide_from;
-  // 64 channels in two planes: 128-step tiles at three blocks to a CU, or 256-step tiles at two (VITS_CHAIN_64_WIDE)
-  static const bool wide64 = getenv("VITS_CHAIN_64_WIDE") ? atoi(getenv("VITS_CHAIN_64_WIDE")) != 0 : false;
-  const int W1 = wide ? 512 : (MT == 2 && NP == 2 && !wide64) ? 128 : 256;
-  const int BN = W1 - 2 * a.R;
-  if (BN < 32) return hipErrorInvalidValue;
-  const size_t lds = (size_t)nch * NP * 2 * (W1 + 2 * a.H) * sizeof(uint4);
-  dim3 grid((a.L + BN - 1) / BN, 1, a.B);
   ConvArgs ta;
   memset(&ta, 0, sizeof ta);
   ta.M = c1[0].M; ta.Cin = c1[0].M; ta.K = 2 * npair * K; ta.L = a.L; ta.B = a.B;    // timing row: every conv's FLOPs
   ta.flags = a.accumulate ? F_ACCUM : 0;                    // bytes: x once, the result once, the sum when accumulated
   char name[64];
   snprintf(name, sizeof name, NP == 1 ? "resblock_chain_bf16_kernel<%d,%d>" : "resblock_chain_kernel<%d,%d>", MT, K);
-  const ProfTicket tk = prof_begin(stream);
-  bool launched = true;
-#define CHAIN_GO(MT_, K_, NP_, WR_, NJ_, BPC_)                                                                     \
-  do {                                                                                                              \
-    static LdsAttr attr;                                                                                            \
-    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(&resblock_chain_kernel<MT_, K_, NP_, WR_, NJ_, BPC_>), lds); \
-        e != hipSuccess)                                                                                            \
-      return e;                                                                                                     \
-    hipLaunchKernelGGL((resblock_chain_kernel<MT_, K_, NP_, WR_, NJ_, BPC_>), grid, dim3(256), lds, stream, a);     \
-  } while (0)
-#define CHAIN_TAPS(MT_, NP_, WR_, NJ_, BPC_)                       \
-  switch (K) {                                                     \
-    case 3: CHAIN_GO(MT_, 3, NP_, WR_, NJ_, BPC_); break;          \
-    case 5: CHAIN_GO(MT_, 5, NP_, WR_, NJ_, BPC_); break;          \
-    case 7: CHAIN_GO(MT_, 7, NP_, WR_, NJ_, BPC_); break;          \
-    case 9: CHAIN_GO(MT_, 9, NP_, WR_, NJ_, BPC_); break;          \
-    case 11: CHAIN_GO(MT_, 11, NP_, WR_, NJ_, BPC_); break;        \
-    default: launched = false;                                     \
+  // Builds (VITS_CHAIN_BUILD_32 / _64: measurement knobs):
+  //   32 channels  0: four waves side by side, 256-step tile (f16x2)    1: the same, 512 steps (bf16: one plane only)
+  //                2: one wave a block, 128 steps -- no block barrier at all; measured slower (f16x2 k = 3: 423 against
+  //                   351 us at 16 x 3 s; bf16: 2699 against 2435 at 64 x 10 s)
+  //   64 channels  bf16: four waves of 64 rows, 256 steps.  f16x2: 1: 2 x 2 waves, 256 steps, two blocks to a CU;
+  //                0: 128 steps, three blocks (k = 3: 722 against 651 us)
+  static const int wide_from = env_int("VITS_CHAIN_WIDE_R", 0);
+  static const int build32 = env_int("VITS_CHAIN_BUILD_32", -1), build64 = env_int("VITS_CHAIN_BUILD_64", 1);
+  if (MT == 1) {
+    int build = build32 >= 0 ? build32 : (NP == 1 && a.R >= wide_from) ? 1 : 0;
+    if (build == 2 && 128 - 2 * a.R < 64) build = NP == 1 ? 1 : 0;       // a 128-step tile would keep too little
+    if (NP == 2) {
+      if (build == 2) return launch_taps<1, 2, 1, 4, 2, 1>(K, a, name, ta, stream);
+      return launch_taps<1, 2, 1, 2, 3, 4>(K, a, name, ta, stream);
+    }
+    if (build == 2) return launch_taps<1, 1, 1, 4, 2, 1>(K, a, name, ta, stream);
+    if (build == 1) return launch_taps<1, 1, 1, 4, 2, 4>(K, a, name, ta, stream);
+    return launch_taps<1, 1, 1, 2, 3, 4>(K, a, name, ta, stream);
   }
-  if (MT == 1 && NP == 2 && K > 5) { CHAIN_TAPS(1, 2, 1, 2, 2) }   // (the long tap loops do not fit three blocks' registers)
-  else if (MT == 1 && NP == 2) { CHAIN_TAPS(1, 2, 1, 2, 3) }       // 32 channels, f16x2: 256-step tile, three blocks to a CU
-  else if (MT == 1 && wide) { CHAIN_TAPS(1, 1, 1, 4, 2) }          // 32 channels, bf16: 512-step tile
-  else if (MT == 1) { CHAIN_TAPS(1, 1, 1, 2, 3) }                  // 32 channels, bf16: 256-step tile
-  else if (NP == 2 && wide64) { CHAIN_TAPS(2, 2, 1, 4, 2) }
-  else if (NP == 2 && K > 3) { CHAIN_TAPS(2, 2, 1, 2, 2) }
-  else if (NP == 2) { CHAIN_TAPS(2, 2, 1, 2, 3) }                  // 64 channels, f16x2: 128-step tile
-  else { CHAIN_TAPS(2, 1, 2, 2, 2) }                               // 64 channels, bf16: every wave all 64 rows, 256 steps
-#undef CHAIN_TAPS
-#undef CHAIN_GO
-  const hipError_t err = launched ? hipGetLastError() : hipErrorInvalidValue;
-  prof_end(tk, name, false, ta, stream);
-  return err;
+  if (NP == 2) {
+    if (build64 == 1 || 128 - 2 * a.R < 32) return launch_taps<2, 2, 1, 4, 2, 4>(K, a, name, ta, stream);
+    return launch_taps<2, 2, 1, 2, 3, 4>(K, a, name, ta, stream);
+  }
+  return launch_taps<2, 1, 2, 2, 2, 4>(K, a, name, ta, stream);
 }
 
 }  // namespace vits
