@@ -99,7 +99,11 @@ int vits_pack_conv_weight_bf16(const float* host_w, int rows, int cin, int taps,
 /* ---- stages of SynthesizerTrn.infer ---- */
 
 /* Conditioning vectors from the speaker embedding: g = emb_g(sid) (reference models.py:719-720) pushed through
- * every cond 1x1 conv (models.py:129,287,551; modules.py:149; frame_prior_network.py:126).  cond: [B, cond_rows]. */
+ * every cond 1x1 conv (models.py:129,287,551; modules.py:149; frame_prior_network.py:126).  cond: [B, cond_rows].
+ * A speaker-less model (n_speakers == 0: the reference runs with g = None, models.py:721-722, and applies no
+ * conditioning conv) has no such call -- vits_speaker_cond fails for it -- and every stage takes an all-zero cond;
+ * its energy must then be given (vits_variance_adaptor with energy_is_tensor), as in the reference, whose energy
+ * predictor cannot run without g (frame_prior_network.py:125). */
 int vits_cond_rows(const vits_model* m);
 int vits_speaker_cond(const vits_model* m, const int64_t* sid, int B, float* cond, int* err_flag, void* stream);
 

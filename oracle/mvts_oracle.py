@@ -130,7 +130,8 @@ class OracleSynthesizer:
     def duration_predictor(self, x, mf, g):
         """reference models.py:125-139"""
         w, p = self.w, "duration_predictor"
-        x = x + F.conv1d(g, w[p + ".cond.weight"], w[p + ".cond.bias"])
+        if g is not None:
+            x = x + F.conv1d(g, w[p + ".cond.weight"], w[p + ".cond.bias"])
         x = torch.relu(F.conv1d(x * mf, w[p + ".conv_1.weight"], w[p + ".conv_1.bias"], padding=1))
         x = channel_layer_norm(x, w[p + ".norm_1.gamma"], w[p + ".norm_1.beta"])
         x = torch.relu(F.conv1d(x * mf, w[p + ".conv_2.weight"], w[p + ".conv_2.bias"], padding=1))
@@ -141,7 +142,8 @@ class OracleSynthesizer:
         """reference models.py:547-556"""
         w, p = self.w, "pitch_predictor"
         mf = mask.to(x.dtype)[:, None, :]
-        x = x + F.conv1d(g, w[p + ".cond.weight"], w[p + ".cond.bias"])
+        if g is not None:
+            x = x + F.conv1d(g, w[p + ".cond.weight"], w[p + ".cond.bias"])
         x = self.encoder(p + ".pitch_net", x * mf, mask) * mf
         return F.conv1d(x, w[p + ".proj_f0.weight"], w[p + ".proj_f0.bias"]).squeeze(1)
 
@@ -149,6 +151,9 @@ class OracleSynthesizer:
         """reference frame_prior_network.py:104-109, 124-129: no masking anywhere."""
         w, p = self.w, "energy_predictor"
         q = p + ".predictor.conv_layer"
+        if g is None:       # the reference calls torch.detach(None) here (frame_prior_network.py:125)
+            raise TypeError("energy_predictor needs the speaker embedding: a speaker-less model runs only with an "
+                            "energy_control tensor")
         x = x + F.conv1d(g, w[p + ".cond.weight"], w[p + ".cond.bias"])
         x = torch.relu(F.conv1d(x, w[q + ".conv_1.conv.weight"], w[q + ".conv_1.conv.bias"], padding=1))
         x = channel_layer_norm(x, w[q + ".layer_norm_1.weight"], w[q + ".layer_norm_1.bias"])
@@ -176,14 +181,14 @@ class OracleSynthesizer:
         w = self.w
         H = x.shape[1]
         out = torch.zeros_like(x)
-        gc = F.conv1d(g, w[p + ".cond_layer.weight"], w[p + ".cond_layer.bias"])
+        gc = None if g is None else F.conv1d(g, w[p + ".cond_layer.weight"], w[p + ".cond_layer.bias"])
         n = 0
         while f"{p}.in_layers.{n}.weight" in w:                 # 4 layers in a flow, 16 in the posterior encoder
             n += 1
         for i in range(n):
             wi = w[f"{p}.in_layers.{i}.weight"]
             x_in = F.conv1d(x, wi, w[f"{p}.in_layers.{i}.bias"], padding=(wi.shape[2] - 1) // 2)
-            a = x_in + gc[:, i * 2 * H:(i + 1) * 2 * H]
+            a = x_in if gc is None else x_in + gc[:, i * 2 * H:(i + 1) * 2 * H]
             acts = torch.tanh(a[:, :H]) * torch.sigmoid(a[:, H:])
             rs = F.conv1d(acts, w[f"{p}.res_skip_layers.{i}.weight"], w[f"{p}.res_skip_layers.{i}.bias"])
             if i < n - 1:
@@ -259,7 +264,8 @@ class OracleSynthesizer:
             def q(t):
                 return t
         x = F.conv1d(q(x), q(w["dec.conv_pre.weight"]), w["dec.conv_pre.bias"], padding=3)
-        x = x + F.conv1d(g, w["dec.cond.weight"], w["dec.cond.bias"])
+        if g is not None:
+            x = x + F.conv1d(g, w["dec.cond.weight"], w["dec.cond.bias"])
         nk = len(self.rb_k)
         for i, (u, ku) in enumerate(self.ups):
             x = F.leaky_relu(x, LRELU_SLOPE)
@@ -298,7 +304,7 @@ class OracleSynthesizer:
         ``stages`` (a dict) receives every stage-boundary tensor."""
         w = self.w
         st = stages if stages is not None else {}
-        g = w["emb_g.weight"][sid].unsqueeze(-1)                                   # :719-720
+        g = w["emb_g.weight"][sid].unsqueeze(-1) if self.n_speakers > 0 else None    # :719-722
         # text encoder, models.py:175-181
         C = w["enc_p.symbol_emb.weight"].shape[1]
         B, P = phonemes.shape

@@ -143,8 +143,9 @@ def test_infer_fp32_grade_modes(synthetic_sd, precision):
         assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= MEL_TOL
 
 
-BF16_WAV_TOL = 3e-2      # plain-bf16 generator against fp32: measured 8e-3 max-abs (rms 1.5e-3, 42 dB below the signal)
-BF16_MEL_TOL = 1e-2      # measured 2.7e-3
+BF16_WAV_TOL = 1.6e-2    # plain-bf16 generator against fp32: twice the measured 8e-3 max-abs (rms 1.5e-3, 42 dB below the signal)
+BF16_MEL_TOL = 5e-3      # twice the measured 2.7e-3
+BF16_RMS_TOL = 3e-3      # against the oracle emulating the same rounding: measured 1e-3
 
 
 def test_infer_bf16_generator_mode(synthetic_sd):
@@ -177,7 +178,7 @@ def test_infer_bf16_generator_mode(synthetic_sd):
         assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= BF16_MEL_TOL
         ref = emu.infer(d["in_phonemes"], d["in_lengths"], sid=d["in_sid"], noise=d["out_noise"], **kw)[0]
         assert metrics.max_abs(o, ref) <= BF16_WAV_TOL
-        assert float((o.cpu() - ref).pow(2).mean().sqrt()) <= 3e-3          # measured 1e-3
+        assert float((o.cpu() - ref).pow(2).mean().sqrt()) <= BF16_RMS_TOL
         assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= BF16_MEL_TOL
 
 
@@ -367,6 +368,55 @@ def test_infer_c3_bf16_fullsize_properties(synthetic_sd, gpu_model):
                    noise_scale=b.noise_scale, duration_control=b.durations[i:i + 1])[0]
     assert metrics.max_abs(o1[0], o[i]) <= BF16_WAV_TOL
     assert not net.range_overflow() and not gpu_model.range_overflow()
+
+
+def test_infer_c3_bf16_row_against_the_oracle(synthetic_sd):
+    """One row of BASELINE configs[2] (batch 1, 160 phonemes, 861 frames = 10 s) with bf16 generator convs against the
+    CPU oracle -- once emulating the same operand rounding (rms bound: single values next to a bf16 rounding boundary
+    flip with the accumulation order, so max-abs is held to the envelope only) and once in fp32 (the envelope) -- so
+    that the full-size bf16 configuration is pinned by something other than this build's own fp32-grade output."""
+    from oracle.mvts_oracle import OracleSynthesizer
+    net = _model(synthetic_sd, "bf16")
+    c3 = synthetic.config_c3()
+    i = 17
+    args = (c3.phonemes[i:i + 1], c3.lengths[i:i + 1])
+    kw = dict(sid=c3.sid[i:i + 1], noise_scale=c3.noise_scale, duration_control=c3.durations[i:i + 1],
+              noise=c3.noise[i:i + 1])
+    o, _, (z, *_), *_ = net.infer(*args, **kw)
+    assert o.shape == (1, 1, 861 * 512)
+    emu_o, _, (emu_z, *_), *_ = OracleSynthesizer(synthetic_sd, generator_bf16=True).infer(*args, **kw)
+    assert metrics.max_abs(z, emu_z) <= LATENT_TOL
+    assert float((o.cpu() - emu_o).pow(2).mean().sqrt()) <= BF16_RMS_TOL
+    assert metrics.max_abs(o, emu_o) <= BF16_WAV_TOL
+    ref = OracleSynthesizer(synthetic_sd).infer(*args, **kw)[0]
+    assert metrics.max_abs(o, ref) <= BF16_WAV_TOL
+    assert metrics.log_mel_l1(o[:, 0], ref[:, 0]) <= BF16_MEL_TOL
+
+
+@pytest.mark.parametrize("name", ["speakerless_given", "speakerless_predicted"])
+def test_infer_speakerless_matches_reference(name):
+    """n_speakers = 0 (reference models.py:719-722: g = None, no conditioning conv applied anywhere), on the calls the
+    reference's own infer can run that way -- energy_control a tensor; without one it raises TypeError
+    (frame_prior_network.py:125), and so does this build.  Vectors from the reference built with n_speakers = 0,
+    gin_channels = 0; sid is ignored, as there."""
+    cfg = synthetic.ModelConfig(n_speakers=0, gin_channels=0)
+    net = _model(synthetic.synthetic_state_dict(cfg, include_enc_q=False), cfg=cfg)
+    d, meta = load_case(name)
+    kw = infer_kwargs(d, meta)
+    o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = net.infer(d["in_phonemes"], d["in_lengths"],
+                                                                       noise=d["out_noise"], **kw)
+    assert torch.equal(x_mask.cpu(), d["out_x_mask"])
+    assert torch.equal(duration.cpu().to(torch.float64), d["out_duration"].to(torch.float64))
+    for got, key in ((m_p, "out_m_p"), (logs_p, "out_logs_p"), (z_p, "out_z_p"), (z, "out_z")):
+        assert metrics.max_abs(got, d[key]) <= LATENT_TOL, key
+    assert metrics.max_abs(o, d["out_o"]) <= WAV_TOL
+    assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= MEL_TOL
+    assert (f0.cpu() - d["out_f0"]).abs().max() <= 1e-3 * max(1.0, float(d["out_f0"].abs().max()))
+    assert metrics.max_abs(energy, d["out_energy"]) <= 1e-3
+    with pytest.raises(TypeError):
+        net.infer(d["in_phonemes"], d["in_lengths"], noise=d["out_noise"], duration_control=d["out_duration"])
+    with pytest.raises(RuntimeError):
+        net.voice_conversion(torch.zeros(1, cfg.spec_channels, 8), torch.tensor([8]), torch.tensor([0]), torch.tensor([1]))
 
 
 def test_infer_c4_corpus_slice(gpu_model, oracle_model):

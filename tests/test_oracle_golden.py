@@ -76,6 +76,29 @@ def test_oracle_matches_reference_resblock2():
     assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= 1e-4
 
 
+SPEAKERLESS = dict(n_speakers=0, gin_channels=0)
+
+
+@pytest.mark.parametrize("name", ["speakerless_given", "speakerless_predicted"])
+def test_oracle_matches_reference_speakerless(name):
+    """A model without speakers (n_speakers = 0: g = None, reference models.py:719-722) on the calls the reference's
+    own infer can run that way -- energy given as a tensor; vectors from the reference built with that option."""
+    from oracle.mvts_oracle import OracleSynthesizer
+    cfg = synthetic.ModelConfig(**SPEAKERLESS)
+    manifest = synthetic.state_dict_manifest(cfg)
+    assert "emb_g.weight" not in manifest and "dec.cond.weight" not in manifest
+    orc = OracleSynthesizer(synthetic.synthetic_state_dict(cfg, include_enc_q=False), n_speakers=0)
+    d, meta = load_case(name)
+    kw = infer_kwargs(d, meta)
+    o, x_mask, (z, *_), duration, f0, energy = orc.infer(d["in_phonemes"], d["in_lengths"], noise=d["out_noise"], **kw)
+    assert torch.equal(x_mask, d["out_x_mask"])
+    assert torch.equal(duration.to(torch.float64), d["out_duration"].to(torch.float64))
+    assert metrics.max_abs(z, d["out_z"]) <= TOL and metrics.max_abs(o, d["out_o"]) <= TOL
+    assert metrics.max_abs(f0, d["out_f0"]) <= 1e-3 and metrics.max_abs(energy, d["out_energy"]) <= 2e-4
+    with pytest.raises(TypeError):               # the reference's energy predictor cannot run without g
+        orc.infer(d["in_phonemes"], d["in_lengths"], noise=d["out_noise"], duration_control=d["out_duration"])
+
+
 def test_oracle_c1_fullsize(oracle_model):
     b = synthetic.config_c1()
     z = np.load(os.path.join(GOLDEN, "c1.npz"))

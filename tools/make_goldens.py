@@ -37,11 +37,13 @@ from oracle import metrics  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
-def load_reference(**model_overrides):
+def load_reference(n_speakers=None, **model_overrides):
     raw = open(os.path.join(REF, "configs/config.json"), "rb").read().decode("gbk")
     raw = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", raw, flags=re.S))
     cfg_json = json.loads(raw)
     cfg_json["model"].update(model_overrides)
+    if n_speakers is not None:
+        cfg_json["data"]["n_speakers"] = n_speakers
     hps = utils.HParams(**cfg_json)
     net = models.SynthesizerTrn(len(symbols), hps.data.filter_length // 2 + 1, hps.data.hop_length,
                                 hps.data.sampling_rate, hps.train.segment_size // hps.data.hop_length,
@@ -150,9 +152,68 @@ def make_resblock2(report):
                         meta_json=np.frombuffer(json.dumps(dict(noise_scale=0.667)).encode(), dtype=np.uint8))
 
 
+SPEAKERLESS = dict(n_speakers=0, gin_channels=0)
+
+
+def make_speakerless(report):
+    """The reference built without speakers (n_speakers = 0, gin_channels = 0: g = None, models.py:719-722) on the one
+    kind of call its infer can run that way -- energy given as a tensor (its energy predictor needs g,
+    frame_prior_network.py:125); durations and pitch predicted in one case, all three given in the other."""
+    cfg = synthetic.ModelConfig(**SPEAKERLESS)
+    net, _ = load_reference(n_speakers=0, gin_channels=0)
+    manifest = synthetic.state_dict_manifest(cfg)
+    ref_sd = net.state_dict()
+    assert list(manifest.keys()) == list(ref_sd.keys()), "speaker-less manifest order/names differ from the reference"
+    for k, shp in manifest.items():
+        assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
+    sd = synthetic.synthetic_state_dict(cfg)
+    net.load_state_dict(sd, strict=True)
+    oracle = OracleSynthesizer(sd, n_speakers=0)
+    b = synthetic.make_batch(19, [11, 8], [38, 26], with_controls=True)
+    cases = {"speakerless_given": dict(noise_scale=0.667, duration_control=b.durations, pitch_control=b.pitch_hz,
+                                       energy_control=b.energy),
+             "speakerless_predicted": dict(noise_scale=0.5, duration_control=1.4, pitch_control=0.9,
+                                           energy_control=b.energy)}
+    for name, kw in cases.items():
+        stages = {}
+        ref = run_reference(net, b, 1900 + len(name), stages, **kw)
+        orc = oracle.infer(b.phonemes, b.lengths, sid=None, noise=ref["noise"], **kw)
+        errs = {"o": metrics.max_abs(orc[0], ref["o"]), "z": metrics.max_abs(orc[2][0], ref["z"]),
+                "f0": metrics.max_abs(orc[4], ref["f0"])}
+        assert torch.equal(orc[1], ref["x_mask"]), name
+        report["cases"][name] = dict(oracle_vs_reference_max_abs=errs, wav_std=float(ref["o"].std()),
+                                     wav_absmax=float(ref["o"].abs().max()),
+                                     frames=[int(v) for v in stages["x_lengths"]])
+        print(name, json.dumps(report["cases"][name]))
+        arrays = {"in_phonemes": b.phonemes, "in_lengths": b.lengths}
+        meta = {}
+        for k, v in kw.items():
+            if isinstance(v, torch.Tensor):
+                arrays["in_" + k] = v
+            else:
+                meta[k] = v
+        arrays.update({"out_" + k: v for k, v in ref.items()})
+        arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **{k: to_np(v) for k, v in arrays.items()})
+    # without an energy tensor the reference cannot run such a model: pin the exception type
+    try:
+        with torch.no_grad():
+            net.infer(b.phonemes, b.lengths, duration_control=b.durations)
+        raise AssertionError("the reference ran a speaker-less model without an energy tensor")
+    except TypeError as e:
+        report["cases"]["speakerless_given"]["without_energy_tensor"] = f"TypeError: {e}"[:120]
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cfg = synthetic.ModelConfig()
+    if "--speakerless-only" in sys.argv:   # add / refresh the speaker-less vectors without touching the others
+        path = os.path.join(OUT, "ORACLE_VS_REFERENCE.json")
+        report = json.load(open(path))
+        make_speakerless(report)
+        with open(path, "w") as f:
+            json.dump(report, f, indent=1)
+        return
     if "--resblock2-only" in sys.argv:   # add / refresh the ResBlock2 vectors without touching the others
         path = os.path.join(OUT, "ORACLE_VS_REFERENCE.json")
         report = json.load(open(path))
@@ -257,6 +318,7 @@ def main():
 
     make_vc(net, oracle, report)
     make_resblock2(report)
+    make_speakerless(report)
 
     # (vi) full-size C1 / C2: every 97th sample, digest, log-mel summary
     for name, batch in (("c1", synthetic.config_c1()), ("c2", synthetic.config_c2())):

@@ -352,7 +352,11 @@ int vits_model_create(const vits_config* cfg, vits_model** out) {
   if (c.n_upsamples <= 0 || c.n_upsamples > 8 || c.n_resblock_kernels <= 0 || c.n_resblock_kernels > 8 ||
       c.n_resblock_dilations <= 0 || c.n_resblock_dilations > 8 || c.resblock < 0 || c.resblock > 2)
     return fail(VITS_ERR_INVALID, "generator: bad upsample / resblock counts or resblock type");
-  if (c.gin_channels <= 0 || c.n_speakers <= 1) return fail(VITS_ERR_INVALID, "a speaker-conditioned model is required (n_speakers > 1, gin_channels > 0)");
+  // n_speakers == 0: speaker-less (no conditioning anywhere; gin_channels is then irrelevant).  n_speakers == 1 is a
+  // configuration the reference itself cannot run (it creates no embedding table for it, models.py:660, and looks a
+  // speaker up all the same, :719)
+  if (c.n_speakers < 0 || c.n_speakers == 1 || (c.n_speakers > 1 && c.gin_channels <= 0))
+    return fail(VITS_ERR_INVALID, "n_speakers must be 0 (speaker-less) or > 1 with gin_channels > 0");
   for (int i = 0; i < c.n_upsamples; ++i) {
     const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
     if (!((u == 8 && k == 16) || (u == 4 && k == 4) || (u == 2 && k == 4)))
@@ -442,7 +446,9 @@ int vits_model_finalize(vits_model* m) {
   const int NR = 2 * c.window_size + 1, DK = C / c.n_heads;
   std::string miss;
   m->symbol_emb = need_plain(m, "enc_p.symbol_emb", (int64_t)c.n_vocab * C, miss);
-  m->emb_g = need_plain(m, "emb_g", (int64_t)c.n_speakers * G, miss);
+  // speaker-less (n_speakers == 0; reference models.py:719-722: g = None): no speaker table, no conditioning matrix;
+  // the caller passes an all-zero conditioning vector instead of calling vits_speaker_cond
+  m->emb_g = c.n_speakers > 0 ? need_plain(m, "emb_g", (int64_t)c.n_speakers * G, miss) : nullptr;
   const int ch0 = c.upsample_initial_channel;
   m->off_dp = 0; m->off_pitch = C; m->off_energy = 2 * C; m->off_dec = 3 * C; m->off_flow = 3 * C + ch0;
   m->cond_rows = m->off_flow + c.n_flows * 2 * C * c.flow_layers;
@@ -466,8 +472,8 @@ int vits_model_finalize(vits_model* m) {
     m->off_encq = m->cond_rows;
     m->cond_rows += 2 * C * nlq;
   }
-  m->cond_w = need_plain(m, "cond.w", (int64_t)m->cond_rows * G, miss);
-  m->cond_b = need_plain(m, "cond.b", m->cond_rows, miss);
+  m->cond_w = c.n_speakers > 0 ? need_plain(m, "cond.w", (int64_t)m->cond_rows * G, miss) : nullptr;
+  m->cond_b = c.n_speakers > 0 ? need_plain(m, "cond.b", m->cond_rows, miss) : nullptr;
   const int nlayers[3] = {c.n_layers, c.pitch_layers, c.n_layers};
   for (int e = 0; e < 3; ++e) {
     m->enc[e].clear();
@@ -671,6 +677,8 @@ int vits_cond_rows(const vits_model* m) { return model_alive(m) && m->finalized 
 
 int vits_speaker_cond(const vits_model* m, const int64_t* sid, int B, float* cond, int* err_flag, void* stream) {
   CHECK_MODEL(m);
+  if (m->cfg.n_speakers == 0)
+    return fail(VITS_ERR_INVALID, "speaker_cond: the model is speaker-less; its conditioning vector is all zeros");
   HIP_TRY(launch_cond_gemv(m->emb_g, sid, m->cond_w, m->cond_b, cond, B, m->cond_rows, m->cfg.gin_channels,
                            m->cfg.n_speakers, err_flag, (hipStream_t)stream));
   return VITS_OK;

@@ -35,8 +35,11 @@ class SynthesizerTrn:
                  freeze_decoder=False, **kwargs):
         if str(resblock) not in ("1", "2"):
             raise ValueError("resblock must be '1' (modules.ResBlock1) or '2' (modules.ResBlock2)")
-        if n_speakers <= 1 or gin_channels <= 0:
-            raise NotImplementedError("a speaker-conditioned model (n_speakers > 1, gin_channels > 0) is required")
+        # n_speakers == 0: speaker-less, g = None everywhere (reference models.py:719-722).  n_speakers == 1 is a
+        # configuration the reference cannot run itself: no embedding table is created for it (models.py:660) and a
+        # speaker is looked up all the same (:719).
+        if n_speakers < 0 or n_speakers == 1 or (n_speakers > 1 and gin_channels <= 0):
+            raise NotImplementedError("n_speakers must be 0 (speaker-less) or > 1 with gin_channels > 0")
         # arithmetic of the conv kernels.  fp32-grade: "f16x2" (default: the generator's convs as three fp16 products
         # of two-term operand splits, everything else bf16x3), "bf16x3" (six bf16 products of three-term splits; full
         # fp32 range) and "fp32" (fp32 MFMA).  "bf16": generator convs in plain bf16, fp32 accumulate.
@@ -142,7 +145,10 @@ class SynthesizerTrn:
                 if k in self._manifest and tuple(v.shape) != tuple(self._manifest[k]):
                     raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)}, model {tuple(self._manifest[k])}")
                 sd[k] = v.detach().to("cpu", torch.float32)
-        needed = [k for k in self._manifest if not k.startswith(weights.UNUSED_PREFIXES)]
+        unused = weights.UNUSED_PREFIXES
+        if self.n_speakers == 0:                 # conditioning convs a speaker-less checkpoint may hold, never applied
+            unused = unused + tuple(k for k in self._manifest if ".cond." in k or ".cond_layer." in k)
+        needed = [k for k in self._manifest if not k.startswith(unused)]
         missing = [k for k in needed if k not in sd]
         if missing:
             raise RuntimeError(f"state dict is missing {len(missing)} tensors the synthesis path needs, e.g. {missing[:4]}")
@@ -445,6 +451,8 @@ class SynthesizerTrn:
         if not self._ready:
             raise RuntimeError("no weights loaded: call load_state_dict / utils.load_checkpoint first")
         lib, h, dev = N.lib, self._handle, self.device
+        if self.n_speakers == 0:
+            raise RuntimeError("voice_conversion needs a speaker-conditioned model")
         pc = lib.vits_posterior_channels(h)
         if pc < 0:
             raise RuntimeError("voice_conversion needs the posterior encoder: load a checkpoint that holds enc_q.*")
@@ -504,9 +512,13 @@ class SynthesizerTrn:
         """Everything of infer() before the generator: reference models.py:717-763."""
         if not self._ready:
             raise RuntimeError("no weights loaded: call load_state_dict / utils.load_checkpoint first")
-        if sid is None:
+        speakers = self.n_speakers > 0
+        if speakers and sid is None:
             # the reference calls self.emb_g(None) here and dies with a TypeError (models.py:719-720)
             raise TypeError("sid is required: the model is speaker-conditioned (n_speakers > 0)")
+        if not speakers and not isinstance(energy_control, torch.Tensor):
+            # g is None, and the reference's energy predictor calls torch.detach(g) (frame_prior_network.py:125)
+            raise TypeError("a speaker-less model (n_speakers == 0) predicts no energy: pass energy_control as a tensor")
         lib, h, dev = N.lib, self._handle, self.device
         cfg = self.cfg
         Cc, IC = cfg.hidden_channels, cfg.inter_channels
@@ -518,12 +530,17 @@ class SynthesizerTrn:
             stream = torch.cuda.current_stream(dev).cuda_stream
             ph = phonemes.to(dev, torch.int64).contiguous()
             lens = phonemes_lengths.to(dev, torch.int32).contiguous()
-            sids = sid.to(dev, torch.int64).contiguous().reshape(-1)
-            if lens.numel() != B or sids.numel() != B:
-                raise ValueError("phonemes_lengths and sid must have one entry per batch row")
+            if lens.numel() != B:
+                raise ValueError("phonemes_lengths must have one entry per batch row")
             err = torch.zeros(1, dtype=torch.int32, device=dev)
-            cond = torch.empty(B, lib.vits_cond_rows(h), **f32)
-            N.check(lib.vits_speaker_cond(h, sids.data_ptr(), B, cond.data_ptr(), err.data_ptr(), stream), "speaker_cond")
+            if speakers:
+                sids = sid.to(dev, torch.int64).contiguous().reshape(-1)
+                if sids.numel() != B:
+                    raise ValueError("sid must have one entry per batch row")
+                cond = torch.empty(B, lib.vits_cond_rows(h), **f32)
+                N.check(lib.vits_speaker_cond(h, sids.data_ptr(), B, cond.data_ptr(), err.data_ptr(), stream), "speaker_cond")
+            else:                                # g = None: no conditioning conv is applied anywhere (sid is ignored)
+                cond = torch.zeros(B, lib.vits_cond_rows(h), **f32)
             # text encoder
             x = torch.empty(B, Cc, P, **f32)
             ws_bytes = max(lib.vits_encoder_workspace_bytes(h, B, P), lib.vits_variance_workspace_bytes(h, B, P))

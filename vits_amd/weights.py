@@ -143,7 +143,11 @@ def prepare(sd: Dict[str, torch.Tensor], cfg, precision: int = N.PREC_F32) -> Pr
         return sd[base + ".bias"].float()
 
     pw.add_plain("enc_p.symbol_emb", sd["enc_p.symbol_emb.weight"])
-    pw.add_plain("emb_g", sd["emb_g.weight"])
+    # a speaker-less model (n_speakers == 0; reference models.py:719-722: g = None) has no speaker table and applies
+    # none of its conditioning convs, whether the checkpoint holds them (gin_channels > 0) or not
+    speakers = cfg.n_speakers > 0
+    if speakers:
+        pw.add_plain("emb_g", sd["emb_g.weight"])
     # attentions.Encoder stacks (reference attentions.py:10-44)
     for prefix, nl_attr in ENCODERS:
         for i in range(getattr(cfg, nl_attr)):
@@ -185,9 +189,12 @@ def prepare(sd: Dict[str, torch.Tensor], cfg, precision: int = N.PREC_F32) -> Pr
     pw.add_plain("energy_prenet.b", sd["energy_prenet.bias"])
     pw.add_conv("project", folded(sd, "project.proj"), bias("project.proj"))
     # conditioning: every 1x1 conv applied to g, stacked into one matrix (order fixed by the library)
-    cw = [folded(sd, "duration_predictor.cond")[:, :, 0], folded(sd, "pitch_predictor.cond")[:, :, 0],
-          folded(sd, "energy_predictor.cond")[:, :, 0], folded(sd, "dec.cond")[:, :, 0]]
-    cb = [bias("duration_predictor.cond"), bias("pitch_predictor.cond"), bias("energy_predictor.cond"), bias("dec.cond")]
+    cw, cb = [], []
+    if speakers:
+        cw = [folded(sd, "duration_predictor.cond")[:, :, 0], folded(sd, "pitch_predictor.cond")[:, :, 0],
+              folded(sd, "energy_predictor.cond")[:, :, 0], folded(sd, "dec.cond")[:, :, 0]]
+        cb = [bias("duration_predictor.cond"), bias("pitch_predictor.cond"), bias("energy_predictor.cond"),
+              bias("dec.cond")]
     # reverse coupling flow (reference models.py:184-216, modules.py:107-172, 294-339)
     nf, nl = cfg.n_flows, cfg.flow_layers
     for f in range(nf):
@@ -212,8 +219,9 @@ def prepare(sd: Dict[str, torch.Tensor], cfg, precision: int = N.PREC_F32) -> Pr
                 pw.add_conv(f"{o}.rs.{l}", w_rs, b_rs)        # both halves as the reference's single conv: one launch
             else:
                 pw.add_conv(f"{o}.skip.{l}", w_rs, b_rs)
-        cw.append(folded(sd, p + ".enc.cond_layer")[:, :, 0])
-        cb.append(bias(p + ".enc.cond_layer"))
+        if speakers:
+            cw.append(folded(sd, p + ".enc.cond_layer")[:, :, 0])
+            cb.append(bias(p + ".enc.cond_layer"))
     # posterior encoder (reference models.py:221-250; voice conversion only): same WN as a flow layer with
     # cfg.enc_q_layers layers; the spectrogram channels of `pre` are zero-padded to a multiple of 16
     if "enc_q.pre.weight" in sd:
@@ -233,10 +241,12 @@ def prepare(sd: Dict[str, torch.Tensor], cfg, precision: int = N.PREC_F32) -> Pr
                 pw.add_conv(f"enc_q.rs.{l}", w_rs, b_rs)
             else:
                 pw.add_conv(f"enc_q.skip.{l}", w_rs, b_rs)
-        cw.append(folded(sd, "enc_q.enc.cond_layer")[:, :, 0])
-        cb.append(bias("enc_q.enc.cond_layer"))
-    pw.add_plain("cond.w", torch.cat(cw, 0))
-    pw.add_plain("cond.b", torch.cat(cb, 0))
+        if speakers:
+            cw.append(folded(sd, "enc_q.enc.cond_layer")[:, :, 0])
+            cb.append(bias("enc_q.enc.cond_layer"))
+    if speakers:
+        pw.add_plain("cond.w", torch.cat(cw, 0))
+        pw.add_plain("cond.b", torch.cat(cb, 0))
     # generator (reference models.py:257-303, modules.py:183-225)
     pw.add_conv("dec.conv_pre", folded(sd, "dec.conv_pre"), bias("dec.conv_pre"))
     n_k = len(cfg.resblock_kernel_sizes)
