@@ -188,6 +188,11 @@ __device__ __forceinline__ void epilogue16(const ConvArgs& a, f32x4 (&acc)[4][NT
 }  // namespace
 
 // S: ring slots of one flat step's weights each (even; the look-ahead is (S - 2) / 2 pair steps).
+#ifdef GL16_STAMP
+__device__ unsigned long long* g_gl16_stamps = nullptr;      // [slots][2]: shader cycles, 100 MHz ticks of a block's main loop
+__device__ unsigned long long g_gl16_stamp_slots = 0;
+#endif
+
 template <int WN, int WGM, int WGN, int K, int S>
 __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
   constexpr int SUBN = WN == 2 ? 2 : 1;          // 16-column tiles per sub-step (the wider wave tiles have 96 / 128
@@ -358,6 +363,12 @@ __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
     }
   };
 
+#ifdef GL16_STAMP
+  // Diagnostic build only (tools/build_variant.sh stamp kernels_gl16.hip -DGL16_STAMP): the shader clock the chip holds
+  // inside the main loop = shader-cycle counter / 100 MHz wall counter, stamped once around the loop.  The values go to a
+  // buffer of their own that nothing else reads; no output depends on them.
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int slot_rd = 0;                               // ring slot of flat step 2p (even); the slots of p - 1 are written
   int p = 0;                                     // pair step
   for (int c0 = 0; c0 < nchunks; c0 += 4) {
@@ -422,6 +433,19 @@ __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
   wait_reads(A[1], B[1]);
   __builtin_amdgcn_sched_barrier(0);
   mma_sub(A[1], B[1], IntC<NSUB - 1>{});
+#ifdef GL16_STAMP
+  {
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* sb = g_gl16_stamps;
+    if (sb && threadIdx.x == 0) {
+      const unsigned long long blk = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z);
+      if (blk < g_gl16_stamp_slots) {
+        sb[2 * blk] = st1 - st0;
+        sb[2 * blk + 1] = rt1 - rt0;
+      }
+    }
+  }
+#endif
   // nothing of this block may still be on its way into LDS when the block's LDS is handed to the next one
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -495,3 +519,13 @@ hipError_t launch_conv_gl16(ConvArgs& a, int bn, hipStream_t stream) {
 }
 
 }  // namespace vits
+
+#ifdef GL16_STAMP
+// Diagnostic build only: where the stamps go (a device buffer of 2 * slots 64-bit words the caller owns).
+extern "C" int vits_debug_gl16_stamp_buffer(void* buf, unsigned long long slots) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(vits::g_gl16_stamps), &p, sizeof p) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(vits::g_gl16_stamp_slots), &slots, sizeof slots) != hipSuccess) return -1;
+  return 0;
+}
+#endif
