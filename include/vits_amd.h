@@ -82,6 +82,15 @@ int vits_model_set_tensor(vits_model* m, const char* name, const float* dev_ptr,
  * rows = packed GEMM rows (cout, or cout*stride for a transposed conv); bias has `rows` entries or is NULL. */
 int vits_model_set_conv(vits_model* m, const char* name, const void* packed_w, const float* bias_rows, int cin,
                         int rows, int taps, int dilation, int mode, int precision);
+/* A second packing of a bf16x3 conv1d's weights in the f16x2 format (same rows / cin / taps; vits_model_set_conv of
+ * that name comes first): launches of that conv too large for the short-sequence kernel -- frame-rate convs of long
+ * batches (the frame-prior encoder, reference models.py:497-501, the projection, :569-572, the flow's WaveNets,
+ * modules.py:144-172) -- then run in f16x2 arithmetic, three fp16 products where bf16x3 takes six bf16 ones.  Optional:
+ * without it such a conv runs in bf16x3 at every size. */
+int vits_model_set_conv_alt(vits_model* m, const char* name, const void* packed_w_f16x2);
+/* When a conv with such a second packing takes it (process-wide; no counterpart in the reference, a tuning knob):
+ * 0 never, 1 (default) launches too large for the short-sequence kernel, 2 always (tests, measurements). */
+void vits_set_front_end_f16x2(int mode);
 /* Resolve every name the synthesis path needs; fails with VITS_ERR_MISSING naming the first absent tensor. */
 int vits_model_finalize(vits_model* m);
 

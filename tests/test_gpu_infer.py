@@ -419,6 +419,31 @@ def test_infer_speakerless_matches_reference(name):
         net.voice_conversion(torch.zeros(1, cfg.spec_channels, 8), torch.tensor([8]), torch.tensor([0]), torch.tensor([1]))
 
 
+def test_frame_rate_convs_in_f16x2_match_the_goldens(gpu_model):
+    """The frame-rate convs of the front end (frame-prior encoder, projection, the flow's WaveNets) carry an f16x2
+    packing beside the bf16x3 one and take it for launches too large for the short-sequence kernel -- long batches, out
+    of the CPU oracle's reach.  Forced on here (vits_set_front_end_f16x2(2)) for the small reference goldens: latents
+    and waveform at the fp32 tolerances, durations and masks (decided at phoneme rate, bf16x3 always) bit-equal."""
+    from vits_amd import _native as N
+    N.lib.vits_set_front_end_f16x2(2)
+    try:
+        for name in ("ragged_b2", "predicted_scalar", "tensor_controls"):
+            d, meta = load_case(name)
+            st = {}
+            o, x_mask, (z, z_p, m_p, logs_p), duration, *_ = gpu_model.infer(
+                d["in_phonemes"], d["in_lengths"], sid=d["in_sid"], noise=d["out_noise"], stages=st, **infer_kwargs(d, meta))
+            assert torch.equal(x_mask.cpu(), d["out_x_mask"])
+            assert torch.equal(duration.cpu().to(torch.float64), d["out_duration"].to(torch.float64))
+            for got, key in ((st["prior"], "stage_prior"), (m_p, "out_m_p"), (logs_p, "out_logs_p"), (z_p, "out_z_p"),
+                             (z, "out_z")):
+                assert metrics.max_abs(got, d[key]) <= LATENT_TOL, key
+            assert metrics.max_abs(o, d["out_o"]) <= WAV_TOL
+            assert metrics.log_mel_l1(o[:, 0], d["out_o"][:, 0]) <= MEL_TOL
+        assert not gpu_model.range_overflow()
+    finally:
+        N.lib.vits_set_front_end_f16x2(1)
+
+
 def test_infer_c4_corpus_slice(gpu_model, oracle_model):
     """BASELINE configs[3] (the 10 000-utterance corpus: lognormal lengths clipped to 88..1400 frames, sorted, cut
     into batches of <= 64): a fixed slice of its batches -- the longest, the shortest, the first ragged one and a

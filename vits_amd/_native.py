@@ -52,6 +52,8 @@ def _load():
         "vits_model_set_range_flag": (i32, [vp, vp]),
         "vits_model_set_tensor": (i32, [vp, C.c_char_p, vp, i64]),
         "vits_model_set_conv": (i32, [vp, C.c_char_p, vp, vp, i32, i32, i32, i32, i32, i32]),
+        "vits_model_set_conv_alt": (i32, [vp, C.c_char_p, vp]),
+        "vits_set_front_end_f16x2": (None, [i32]),
         "vits_model_finalize": (i32, [vp]),
         "vits_pack_conv_weight": (i32, [vp, i32, i32, i32, vp]),
         "vits_pack_conv_weight_bf16x3": (i32, [vp, i32, i32, i32, vp]),

@@ -52,6 +52,10 @@ struct ConvDesc {          // one packed convolution, immutable after load
   const void* w = nullptr;       // PREC_F32: fp32 [Cin/16][K][2][M/32][64][4]; PREC_BF16X3: bf16 [Cin/16][K][M/32][3][64][8]; PREC_BF16: bf16 [Cin/16][K][M/32][64][8];
                                  // PREC_F16X2: fp16 [Cin/16][K][M/32][2][64][8]
   int prec = PREC_F32;
+  // optional second packing of the same weights for PREC_F16X2 (a PREC_BF16X3 conv of the front end): launches too
+  // large for the split-K kernel -- frame-rate convs of long batches -- then run three fp16 products instead of six
+  // bf16 ones; short launches, where masks and durations are decided, keep bf16x3
+  const void* w_alt = nullptr;
   const float* bias = nullptr;   // [M] per-row bias, may be null
   int Cin = 0, M = 0, K = 0, mode = MODE_PLAIN;
   int toff0[2] = {0, 0};         // input time offset of tap k, per row class: toff0 + k * tstep
@@ -147,6 +151,8 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
 // true when launch_conv would run this conv on the split-K kernel for a batch of B rows of L steps (the only kernel
 // that honours ConvArgs::ln_*)
 bool conv_takes_split_k(const ConvDesc& d, int B, int L);
+void set_alt_f16x2_mode(int mode);      // ConvDesc::w_alt: 0 never, 1 launches beyond the split-K kernel (default), 2 always
+int alt_f16x2_mode();
 
 // One ResBlock pair in one launch (32-channel stage, PREC_F16X2): out = x + c2(lrelu(c1(lrelu(x)))) [+ out], with the
 // tensor between the two convs kept in LDS.  x and out must not overlap (blocks read a halo of x).

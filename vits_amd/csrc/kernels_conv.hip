@@ -2528,6 +2528,7 @@ static int ks_choice(bool gate, int M, int Cin, int K, int L, int B, int halo, b
 
 bool conv_takes_split_k(const ConvDesc& d, int B, int L) {
   bool eight;
+  if (d.w_alt && alt_f16x2_mode() >= 2) return false;
   return d.prec == PREC_BF16X3 && (d.mode == MODE_PLAIN || d.mode == MODE_GATE) &&
          ks_choice(d.mode == MODE_GATE, d.M, d.Cin, d.K, L, B, d.max_off - d.min_off, &eight) > 0;
 }
@@ -2566,6 +2567,16 @@ static int small128_limit() {
   return n;
 }
 
+// When a bf16x3 conv that carries an f16x2 packing (ConvDesc::w_alt) takes it: 0 never, 1 (default) for launches too
+// large for the split-K kernel, 2 always (tests and measurements: the split-K kernel is then bypassed for such convs).
+// VITS_FE_F16X2 sets the initial value.
+static std::atomic<int> g_alt_mode{[] {
+  const char* e = getenv("VITS_FE_F16X2");
+  return e && e[0] ? atoi(e) : 1;
+}()};
+void set_alt_f16x2_mode(int mode) { g_alt_mode.store(mode < 0 ? 0 : mode > 2 ? 2 : mode); }
+int alt_f16x2_mode() { return g_alt_mode.load(); }
+
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   if (d.Cin % 16 != 0 || d.M % 32 != 0 || d.K < 1 || d.K > MAX_TAPS) return hipErrorInvalidValue;
   if (d.max_off - d.min_off > MAX_HALO) return hipErrorInvalidValue;
@@ -2584,7 +2595,8 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
     a.toff0[c] = d.toff0[c];
     a.tstep[c] = d.tstep[c];
   }
-  const int L = a.L, M = d.M, p = d.prec;
+  const int L = a.L, M = d.M;
+  int p = d.prec;
   if ((a.flags & (F_IN_STAGED | F_OUT_STAGED)) && (d.mode != MODE_PLAIN || (p != PREC_BF16 && p != PREC_F16X2)))
     return hipErrorInvalidValue;
   if ((a.flags & F_OUT_STAGED) && (a.flags & (F_RELU | F_MASK_PRE | F_RES | F_RES_SUB | F_ACCUM | F_MASK_POST)))
@@ -2603,10 +2615,20 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
     if (a.ln_res_stats && (!a.res || !a.ln_res_gamma || !a.ln_res_beta)) return hipErrorInvalidValue;
   }
   if (p == PREC_BF16X3 && (d.mode == MODE_PLAIN || d.mode == MODE_GATE)) {
-    hipError_t err = hipSuccess;
-    ConvArgs ak = a;
-    if (d.mode == MODE_PLAIN ? try_launch_ks<MODE_PLAIN>(ak, stream, err) : try_launch_ks<MODE_GATE>(ak, stream, err))
-      return err;
+    // the f16x2 packing, where the conv has one and uses nothing the f16x2 kernel's epilogue is not built with (a
+    // second destination, deferred LayerNorm)
+    const bool alt_ok = d.w_alt && !a.split_row && !a.ln_in_stats && !a.ln_res_stats && !a.ln_out_stats && M % 64 == 0;
+    const int alt = alt_ok ? alt_f16x2_mode() : 0;
+    if (alt < 2) {
+      hipError_t err = hipSuccess;
+      ConvArgs ak = a;
+      if (d.mode == MODE_PLAIN ? try_launch_ks<MODE_PLAIN>(ak, stream, err) : try_launch_ks<MODE_GATE>(ak, stream, err))
+        return err;
+    }
+    if (alt > 0) {                               // too large for the split-K kernel (or forced)
+      a.w = d.w_alt;
+      p = PREC_F16X2;
+    }
   }
   switch (d.mode) {
     case MODE_PLAIN:

@@ -191,6 +191,7 @@ ConvArgs base_args(const float* x, long long x_bs, int x_cs, float* out, long lo
   a.out = out; a.out_bs = out_bs; a.out_cs = out_cs;
   a.B = B; a.L = L; a.lengths = lengths; a.flags = flags;
   a.in_scale = 1.f; a.in_slope = 1.f;
+  a.range_flag = g_range_flag;
   return a;
 }
 
@@ -433,6 +434,17 @@ int vits_model_set_conv(vits_model* m, const char* name, const void* w, const fl
   ConvDesc d;
   TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode, precision));
   m->convs[name] = d;
+  m->finalized = false;
+  return VITS_OK;
+}
+
+int vits_model_set_conv_alt(vits_model* m, const char* name, const void* w_f16x2) {
+  if (!model_alive(m) || !name || !w_f16x2) return fail(VITS_ERR_INVALID, "set_conv_alt: bad argument");
+  auto it = m->convs.find(name);
+  if (it == m->convs.end()) return fail(VITS_ERR_MISSING, "set_conv_alt: no such conv (vits_model_set_conv comes first)");
+  if (it->second.prec != PREC_BF16X3 || (it->second.mode != MODE_PLAIN && it->second.mode != MODE_GATE))
+    return fail(VITS_ERR_INVALID, "set_conv_alt: only a bf16x3 conv1d takes a second packing");
+  it->second.w_alt = w_f16x2;
   m->finalized = false;
   return VITS_OK;
 }
@@ -787,6 +799,7 @@ int vits_frame_prior(const vits_model* m, float* x_frame, const int* frame_lengt
                      float noise_scale, float* stats, float* z_p, float* z, void* ws, int64_t ws_bytes, void* stream) {
   CHECK_MODEL(m);
   hipStream_t s = (hipStream_t)stream;
+  RangeFlagScope range_scope(m->range_flag);       // frame-rate convs of long batches run in f16x2
   if (T > 16384) return fail(VITS_ERR_INVALID, "at most 16384 frames per utterance");
   Arena ar(ws, ws_bytes);
   TRY(run_encoder(m, 2, x_frame, frame_lengths, B, T, ar, s));
@@ -839,6 +852,7 @@ static int run_flow(const vits_model* m, float* z, const int* lengths, const flo
                     int64_t ws_bytes, hipStream_t s, bool reverse) {
   const int C = m->cfg.hidden_channels, IC = m->cfg.inter_channels, half = IC / 2, NL = m->cfg.flow_layers;
   const int cr = m->cond_rows, nf = m->cfg.n_flows;
+  RangeFlagScope range_scope(m->range_flag);       // frame-rate convs of long batches run in f16x2
   Arena ar(ws, ws_bytes);
   float* h = ar.take((int64_t)B * C * T);
   float* acts = ar.take((int64_t)B * C * T);
@@ -1153,6 +1167,8 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
                           ch0 >> c.n_upsamples, 7, L, F_IN_LRELU, in_scale, 0.01f, true, false, s));
   return VITS_OK;
 }
+
+void vits_set_front_end_f16x2(int mode) { set_alt_f16x2_mode(mode); }
 
 // ---- per-kernel timing ----
 void vits_profile_enable(int on) { prof_enable(on != 0); }

@@ -198,6 +198,10 @@ class SynthesizerTrn:
                 N.check(N.lib.vits_model_set_conv(h, name.encode(), dw.data_ptr(), N.ptr(db), cin, rows, taps, dil, mode,
                                                   prec),
                         f"set_conv {name}")
+            for name, w in getattr(pw, "alts", {}).items():
+                dw = w.to(self.device)
+                self._device_tensors.append(dw)
+                N.check(N.lib.vits_model_set_conv_alt(h, name.encode(), dw.data_ptr()), f"set_conv_alt {name}")
             N.check(N.lib.vits_model_finalize(h), "vits_model_finalize")
             self._range = torch.zeros(1, dtype=torch.int32, device=self.device)
             N.check(N.lib.vits_model_set_range_flag(h, self._range.data_ptr()), "set_range_flag")

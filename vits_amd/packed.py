@@ -12,8 +12,9 @@ and then ``SynthesizerTrn.from_packed("model.vitsw")`` uploads the mapped bytes 
 File layout: 8-byte magic ``VITSAMD1``, uint64 little-endian header length, a JSON header, then the tensors, each at a
 256-byte-aligned offset counted from the end of the header.  The header holds the format version, the model
 configuration, the model-level precision and one record per tensor: ``{name, dtype, numel, offset}`` for plain
-tensors, and for convs ``{name, dtype, numel, offset, bias_offset (or -1), cin, rows, taps, dilation, mode,
-precision}``."""
+tensors, for convs ``{name, dtype, numel, offset, bias_offset (or -1), cin, rows, taps, dilation, mode,
+precision}``, and ``{kind: "alt", name, dtype, numel, offset}`` for the second (f16x2) packing some front-end convs
+carry."""
 from __future__ import annotations
 
 import dataclasses
@@ -91,6 +92,8 @@ def save_packed(path: str, state_dict: Dict[str, torch.Tensor], cfg=None, precis
         if b is not None:
             rec["bias_offset"] = place(b)
         records.append(rec)
+    for name, w in pw.alts.items():           # second (f16x2) packing of a conv recorded above
+        records.append(dict(kind="alt", name=name, dtype="int16", numel=w.numel(), offset=place(w)))
     header = dict(version=VERSION, precision=precision, config=_cfg_to_json(cfg), data_bytes=off, tensors=records)
     hb = json.dumps(header).encode()
     hb += b" " * (-(16 + len(hb)) % _ALIGN)                   # data starts on a 256-byte boundary of the file
@@ -146,6 +149,8 @@ def load_packed(path: str) -> Tuple[object, str, weights.PreparedWeights]:
             t = view(r["offset"], r["numel"], r["dtype"])
             if r["kind"] == "plain":
                 pw.plain[r["name"]] = t
+            elif r["kind"] == "alt":
+                pw.alts[r["name"]] = t
             else:
                 b = None if r["bias_offset"] < 0 else view(r["bias_offset"], r["rows"], "float32")
                 pw.convs[r["name"]] = (t, b, r["cin"], r["rows"], r["taps"], r["dilation"], r["mode"], r["precision"])

@@ -113,6 +113,9 @@ class PreparedWeights:
         self.precision = precision
         self.plain: Dict[str, torch.Tensor] = {}
         self.convs: Dict[str, Tuple[torch.Tensor, torch.Tensor, int, int, int, int, int, int]] = {}
+        # second packing (f16x2) of bf16x3 front-end convs that run at frame rate: the library takes it for launches
+        # too large for its short-sequence kernel (vits_model_set_conv_alt)
+        self.alts: Dict[str, torch.Tensor] = {}
 
     def conv_precision(self, name: str) -> int:
         if self.precision in (N.PREC_BF16, N.PREC_F16X2) and not name.startswith("dec."):
@@ -127,7 +130,18 @@ class PreparedWeights:
         b = None if bias_rows is None else bias_rows.detach().float().contiguous()
         prec = self.conv_precision(name)
         self.convs[name] = (pack_rows(w_rows, prec), b, cin, rows, taps, dilation, mode, prec)
+        if (prec == N.PREC_BF16X3 and self.precision in (N.PREC_BF16, N.PREC_F16X2) and name.startswith(FRAME_RATE_CONVS)
+                and mode in (N.MODE_PLAIN, N.MODE_GATE) and rows % 64 == 0 and cin % 16 == 0):
+            try:
+                self.alts[name] = pack_rows(w_rows, N.PREC_F16X2)
+            except Exception:                    # a weight outside the fp16 range: this conv stays bf16x3 at every size
+                pass
 
+
+# convs that run once per FRAME (frame-prior encoder, projection, coupling flow): at long batches they are matrix-bound
+# and get an f16x2 packing beside the bf16x3 one; everything at phoneme rate (text encoder, the predictors: where
+# durations and masks are decided) has bf16x3 only
+FRAME_RATE_CONVS = ("frame_prior_net.fft_block.", "project", "flow.")
 
 ENCODERS = (("enc_p.encoder", "n_layers"), ("pitch_predictor.pitch_net", "pitch_layers"),
             ("frame_prior_net.fft_block", "n_layers"))
