@@ -16,8 +16,9 @@ import sys
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and ("vits::conv_" in r["Kernel_Name"] or "vits::resblock_pair" in r["Kernel_Name"]):
-            name = r["Kernel_Name"].replace("void ", "").replace("vits::", "").split("(")[0]
+        kn = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+        if r["Counter_Name"] == counter and ("vits::conv_" in kn or "vits::resblock_pair" in kn or "vits::resblock_chain" in kn):
+            name = kn.replace("void ", "").replace("vits::", "").split("(")[0]
             name = re.sub(r"\s+", "", name)
             # the library's timing rows call the staged-input instantiations "...,staged>" and leave "false" out
             # (and the small-grid build "...,staged,6>" / "...,false,6>"; the profiler prints the template arguments
@@ -27,6 +28,9 @@ def per_kernel(path, counter):
             # (and its fourth the row tiles per wave, which the timing rows leave out)
             name = re.sub(r"resblock_pair_kernel<(\d+),(\d+),2(,\d+)?>", r"resblock_pair_kernel<\1,\2>", name)
             name = re.sub(r"resblock_pair_kernel<(\d+),(\d+),1(,\d+)?>", r"resblock_pair_bf16_kernel<\1,\2>", name)
+            # the whole-ResBlock kernel: <channels / 32, taps, planes, ...build parameters>; rows name (channels / 32, taps)
+            name = re.sub(r"resblock_chain_kernel<(\d+),(\d+),2(,\d+)*>", r"resblock_chain_kernel<\1,\2>", name)
+            name = re.sub(r"resblock_chain_kernel<(\d+),(\d+),1(,\d+)*>", r"resblock_chain_bf16_kernel<\1,\2>", name)
             name = name.replace("conv_glb_kernel<", "conv_glb_bf16_kernel<")     # the timing row names its arithmetic
             name = name.replace(",false,0>", ">").replace(",true>", ",staged>").replace(",false>", ">")
             acc[name].append(float(r["Counter_Value"]) * 1024.0)

@@ -11,7 +11,7 @@ import sys
 
 
 def short(name):
-    return name.replace("vits::", "").replace("void ", "").split("(")[0]
+    return name.replace("(anonymous namespace)::", "").replace("vits::", "").replace("void ", "").split("(")[0]
 
 
 def rows_from_csv(d):

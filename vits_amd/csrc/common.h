@@ -112,6 +112,26 @@ __device__ __forceinline__ int xcd_tile(int bx, int ntiles, int on) {
   return f * q + (f < r ? f : r) + (bx >> 3);
 }
 
+// Time tile and row block of a block of a grid of ntiles x 2 blocks per batch row (a 256-row layer in 128-row blocks).
+// The two row blocks of a time tile read the same activation tile; workgroups are dealt to the XCDs round-robin in
+// launch order (x fastest), so with the plain mapping the two sit ntiles apart, on different XCDs as a rule, and the
+// tile is fetched from memory twice.  Here the blocks l and l + 8 of a plane -- same XCD, consecutive in its queue --
+// are the two row blocks of one tile, so the second finds the tile in the XCD's L2.  A bijection for any ntiles: the
+// last (2 ntiles) % 16 blocks of a plane keep row blocks side by side.
+__device__ __forceinline__ void xcd_tile_rows2(int bx, int by, int ntiles, int on, int& tile, int& rowblk) {
+  if (!on) { tile = bx; rowblk = by; return; }
+  const int l = bx + ntiles * by, full = (2 * ntiles) & ~15;
+  if (l < full) {
+    const int q = l >> 3;
+    tile = ((q >> 1) << 3) + (l & 7);
+    rowblk = q & 1;
+  } else {
+    const int r = l - full;
+    tile = (full >> 1) + (r >> 1);
+    rowblk = r & 1;
+  }
+}
+
 // mean and 1 / sqrt(var + eps) of one time step from the per-unit partial statistics (Chan's combination of
 // (sum, M2) pairs over units of 64 channels)
 __device__ __forceinline__ void ln_combine(const float* __restrict__ st, int units, float& mean, float& rstd) {

@@ -377,7 +377,7 @@ static int chain_radius(const ConvDesc* c1, int npair) {
 }
 
 bool chain_fusable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
-  if (npair < 2 || npair > CHAIN_MAX_PAIRS) return false;
+  if (npair < 1 || npair > CHAIN_MAX_PAIRS) return false;
   for (int p = 0; p < npair; ++p) {
     if (!pair_fusable(c1[p], c2[p])) return false;
     if (c1[p].M != c1[0].M || c1[p].K != c1[0].K || c1[p].prec != c1[0].prec) return false;

@@ -1441,8 +1441,10 @@ __global__ __launch_bounds__(256, 2) void conv_gl_kernel(const ConvArgs a) {
   const int wm = wave / WGN, wn = wave % WGN;
   const int par = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z;
-  const int t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
-  const int mt0 = blockIdx.y * (BM / 32);
+  int tile = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map), rowblk = blockIdx.y;
+  if (gridDim.y == 2) xcd_tile_rows2(blockIdx.x, blockIdx.y, gridDim.x, a.xcd_map, tile, rowblk);
+  const int t0 = tile * BN;
+  const int mt0 = rowblk * (BM / 32);
   int mt[WM];
   bool mt_ok[WM];
 #pragma unroll
@@ -1671,8 +1673,10 @@ __global__ __launch_bounds__(256, 2) void conv_glb_kernel(const ConvArgs a) {
   const int wm = wave / WGN, wn = wave % WGN;
   const int par = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z;
-  const int t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
-  const int mt0 = blockIdx.y * HP;
+  int tile = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map), rowblk = blockIdx.y;
+  if (gridDim.y == 2) xcd_tile_rows2(blockIdx.x, blockIdx.y, gridDim.x, a.xcd_map, tile, rowblk);
+  const int t0 = tile * BN;
+  const int mt0 = rowblk * HP;
   int mt[WM];
   bool mt_ok[WM];
 #pragma unroll

@@ -221,8 +221,10 @@ __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
   const int b = blockIdx.z;
-  const int t0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map) * BN;
-  const int mt0 = blockIdx.y * (BM / 32);
+  int tile = xcd_tile(blockIdx.x, gridDim.x, a.xcd_map), rowblk = blockIdx.y;
+  if (gridDim.y == 2) xcd_tile_rows2(blockIdx.x, blockIdx.y, gridDim.x, a.xcd_map, tile, rowblk);
+  const int t0 = tile * BN;
+  const int mt0 = rowblk * (BM / 32);
   const int nchunks = a.Cin / 16;
   const int total = nchunks * K;
   const int tstart = t0 + a.min_off;
