@@ -440,6 +440,7 @@ def _ptr_array(tensors):
     ("f16x2", 64, 3, (1, 3, 5), 104, 1, False), ("f16x2", 32, 7, (1, 3, 5), 1500, 2, True),
     ("f16x2", 32, 11, (1, 3, 5), 700, 1, False), ("f16x2", 64, 7, (1, 3, 5), 333, 1, False),
     ("f16x2", 32, 3, (1, 2), 500, 2, False), ("f16x2", 32, 5, (1, 3, 5, 2), 40, 3, True),
+    ("f16x2", 64, 11, (3,), 300, 2, True), ("bf16", 64, 11, (1, 3), 700, 1, False),
     ("bf16", 32, 3, (1, 3, 5), 1000, 2, True), ("bf16", 32, 7, (1, 3, 5), 1761, 2, False),
     ("bf16", 32, 11, (1, 3, 5), 1200, 1, True), ("bf16", 64, 3, (1, 3, 5), 465, 2, True),
     ("bf16", 64, 7, (1, 3, 5), 900, 2, False), ("bf16", 64, 11, (1, 3, 5), 300, 1, True),
@@ -489,8 +490,8 @@ def test_resblock_chain_fused(N, prec, C, k, dils, L, B, acc):
 
 
 def test_resblock_chain_refuses_unsupported_shapes(N):
-    """One pair only (the pair kernel's job), five pairs, halos that add up to more than 64 steps a side, in-place
-    use and other channel counts are errors, never launches."""
+    """Five pairs, halos that add up to more than 64 steps a side, in-place use and other channel or tap counts are
+    errors, never launches."""
     import ctypes as Ct
     from vits_amd import weights
     p = PREC["f16x2"]
@@ -505,7 +506,7 @@ def test_resblock_chain_refuses_unsupported_shapes(N):
                                             _ptr_array([b] * n), C, k, (Ct.c_int * n)(*dils), n, p, x.data_ptr(),
                                             (x if in_place else out).data_ptr(), 1, 64, 0, 0.1, stream)
     assert call(32, 3, (1, 3, 5)) == 0
-    assert call(32, 3, (1,)) != 0 and call(32, 3, (1, 1, 1, 1, 1)) != 0
+    assert call(32, 3, (1,)) == 0 and call(32, 3, (1, 1, 1, 1, 1)) != 0
     assert call(32, 11, (5, 5, 5)) != 0 and call(96, 3, (1, 3, 5)) != 0 and call(32, 4, (1, 3, 5)) != 0
     assert call(32, 3, (1, 3, 5), in_place=True) != 0
     torch.cuda.synchronize()

@@ -196,6 +196,9 @@ hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const Pa
 bool chain_fusable(const ConvDesc* c1, const ConvDesc* c2, int npair);      // the kernel supports the chain
 bool chain_profitable(const ConvDesc* c1, const ConvDesc* c2, int npair);   // ... and is the faster choice for it
 hipError_t launch_resblock_chain(const ConvDesc* c1, const ConvDesc* c2, int npair, const PairArgs& a, hipStream_t stream);
+// the launches a ResBlock is cut into: seg[i] consecutive pairs each (a segment of one pair is a fused-pair launch);
+// returns their number, 0 when the ResBlock has no such plan
+int chain_plan(const ConvDesc* c1, const ConvDesc* c2, int npair, int* seg);
 
 // Optional per-kernel timing of the conv launches with HIP events on the launch stream (off by default).
 struct ProfRow {

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
 #ifndef CHAIN_RING3
 #define CHAIN_RING3 4
 #endif
-  constexpr int D = chain_ring(2 * NT, BPC >= 3 ? (NP == 2 ? CHAIN_RING3 : 4) : WR == 2 ? 6 : (NJ == 4 && NP == 2) ? 3 : 8);
+  constexpr int D = chain_ring(2 * NT, BPC >= 3 ? (NP == 2 ? CHAIN_RING3 : 4) : WR == 2 ? 4 : (NJ == 4 && NP == 2) ? 3 : 8);
   static_assert((2 * NT) % D == 0 && D >= 2, "ring slots must line up across pairs");
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -162,22 +162,23 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
-  auto mma = [&](const uint4 (&af)[WR][NP], int pa, const uint4 (&bf)[NJ]) __attribute__((always_inline)) {
+  auto mma = [&](const uint4 (&af)[WR][NP], int pa, const auto& bf, int j0) __attribute__((always_inline)) {
+    constexpr int NB = sizeof(bf) / sizeof(uint4);          // n-tiles j0 .. j0 + NB - 1
 #pragma unroll
     for (int i = 0; i < WR; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      for (int jj = 0; jj < NB; ++jj) {
+        const int j = j0 + jj;
         if constexpr (CHAIN_KO & 1) {
-          acc[i][j][0] += __builtin_bit_cast(float, af[i][pa].x ^ bf[j].x);
+          acc[i][j][0] += __builtin_bit_cast(float, af[i][pa].x ^ bf[jj].x);
         } else if constexpr (NP == 2)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][pa]),
-                                                             __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
+                                                             __builtin_bit_cast(f16x8, bf[jj]), acc[i][j], 0, 0, 0);
         else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][pa]),
-                                                              __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+                                                              __builtin_bit_cast(bf16x8, bf[jj]), acc[i][j], 0, 0, 0);
       }
   };
-  // one conv over the operand tile: output column c reads tile columns c - reach + k * step
   // LDS addresses: one vector register per conv (the lane's column and half, made opaque so that nothing derived from
   // it is computed ahead and kept), plus per tap a wave-uniform offset -- chunk, and for the dilated conv tap * stride,
   // a run-time value made opaque at every tap -- added where the tap is read; n-tile, and for the undilated conv the
@@ -198,23 +199,30 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
           asm volatile("" : "+s"(uni));
         }
         const int off = base + uni + (decltype(dilated)::value != 0 ? 0 : k);
-        uint4 Bh[NJ], Bl[NJ];
+        // the activation fragments of JG n-tiles at a time (all of them, or two where four in two planes would be 32
+        // registers in flight); each accumulator still takes its tap's products in the order h * l, h * h, l * h
+        constexpr int JG = (NJ == 4 && NP == 2) ? 2 : NJ;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if constexpr (CHAIN_KO & 8) {
-            Bh[j] = make_uint4(off, j, k, chunk);
-            Bl[j] = make_uint4(j, off, chunk, k);
-          } else {
-            Bh[j] = lds[off + j * 32];
-            if constexpr (NP == 2) Bl[j] = lds[2 * COLS + off + j * 32];
+        for (int j0 = 0; j0 < NJ; j0 += JG) {
+          uint4 Bh[JG], Bl[JG];
+#pragma unroll
+          for (int j = 0; j < JG; ++j) {
+            if constexpr (CHAIN_KO & 8) {
+              Bh[j] = make_uint4(off, j, k, chunk);
+              Bl[j] = make_uint4(j, off, chunk, k);
+            } else {
+              Bh[j] = lds[off + (j0 + j) * 32];
+              if constexpr (NP == 2) Bl[j] = lds[2 * COLS + off + (j0 + j) * 32];
+            }
           }
-        }
-        if constexpr (NP == 2) {
-          mma(Aq[g % D], 0, Bl);                           // h * l
-          mma(Aq[g % D], 0, Bh);                           // h * h
-          mma(Aq[g % D], NP - 1, Bh);                      // l * h
-        } else {
-          mma(Aq[g % D], 0, Bh);
+          if constexpr (NP == 2) {
+            mma(Aq[g % D], 0, Bl, j0);                     // h * l
+            mma(Aq[g % D], 0, Bh, j0);                     // h * h
+            mma(Aq[g % D], NP - 1, Bh, j0);                // l * h
+          } else {
+            mma(Aq[g % D], 0, Bh, j0);
+          }
+          if constexpr (JG != NJ) __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (!(CHAIN_KO & 2)) fetch_a(g + D);
 #ifdef CHAIN_SCHED_BARRIER
@@ -428,6 +436,26 @@ int env_int(const char* name, int dflt) {
   return e && e[0] ? atoi(e) : dflt;
 }
 }  // namespace
+
+// How a ResBlock of npair pairs is cut into launches: seg[i] pairs each, in order.  One segment = the whole ResBlock
+// in one launch; segments of one pair go to the pair kernel; 0 = no plan (every pair on its own, by whatever path the
+// caller has for it).  Beyond the whole-ResBlock list: 64 channels, 11 taps in plain bf16 -- the whole block loses too
+// many columns a side (60 of a 256-step tile) but its first two pairs lose as many as its third alone (30), and fused
+// they take 6.4 ms where two pair launches take 7.4 (64 x 10 s).  VITS_CHAIN_SPLIT=0 switches that off.
+int chain_plan(const ConvDesc* c1, const ConvDesc* c2, int npair, int* seg) {
+  if (chain_profitable(c1, c2, npair)) {
+    seg[0] = npair;
+    return 1;
+  }
+  static const bool split = env_int("VITS_CHAIN_SPLIT", 1) != 0;
+  if (split && npair == 3 && c1[0].prec == PREC_BF16 && c1[0].M == 64 && c1[0].K == 11 && chain_fusable(c1, c2, 2) &&
+      pair_fusable(c1[2], c2[2])) {
+    seg[0] = 2;
+    seg[1] = 1;
+    return 2;
+  }
+  return 0;
+}
 
 hipError_t launch_resblock_chain(const ConvDesc* c1, const ConvDesc* c2, int npair, const PairArgs& pa, hipStream_t stream) {
   if (!chain_fusable(c1, c2, npair) || pa.B <= 0 || pa.L <= 0 || pa.B > 65535) return hipErrorInvalidValue;

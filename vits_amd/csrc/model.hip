@@ -1099,15 +1099,26 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
       // T before reading it.  So a chain is fused only when every one of its pairs is.
       bool fuse_chain = fused_pairs_enabled() && !single;
       for (int q = 0; q < nd && fuse_chain; ++q) fuse_chain = pair_profitable(rb.c1[q], rb.c2[q]);
-      if (whole_resblocks_enabled() && !single && chain_profitable(rb.c1.data(), rb.c2.data(), nd)) {
-        // the whole ResBlock in one launch: x is read once, the chain's result goes straight into the stage's sum
-        if (j > 0 && n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
-        PairArgs pa;
-        pa.x = X; pa.x_bs = (long long)rb.c1[0].Cin * L; pa.x_cs = L;
-        pa.out = XS; pa.out_bs = (long long)rb.c1[0].Cin * L; pa.out_cs = L;
-        pa.B = B; pa.L = L; pa.accumulate = j > 0; pa.slope = 0.1f;
-        pa.range_flag = g_range_flag;
-        HIP_TRY(launch_resblock_chain(rb.c1.data(), rb.c2.data(), nd, pa, sj));
+      int seg[8];
+      const int nseg = whole_resblocks_enabled() && !single && nd <= 8 ? chain_plan(rb.c1.data(), rb.c2.data(), nd, seg) : 0;
+      if (nseg > 0) {
+        // the ResBlock in nseg launches (one: x is read once and the result goes straight into the stage's sum); the
+        // carrier between two segments takes turns in Y and T
+        int q0 = 0;
+        for (int g = 0; g < nseg; ++g) {
+          const bool last = g + 1 == nseg;
+          float* dst = last ? XS : ((g & 1) ? Tt[j] : Y[j]);
+          if (last && j > 0 && n_side > 0) HIP_TRY(hipStreamWaitEvent(sj, m->ev_done[j - 1], 0));
+          PairArgs pa;
+          pa.x = yin; pa.x_bs = (long long)rb.c1[0].Cin * L; pa.x_cs = L;
+          pa.out = dst; pa.out_bs = (long long)rb.c1[0].Cin * L; pa.out_cs = L;
+          pa.B = B; pa.L = L; pa.accumulate = last && j > 0; pa.slope = 0.1f;
+          pa.range_flag = g_range_flag;
+          if (seg[g] == 1) HIP_TRY(launch_resblock_pair(rb.c1[q0], rb.c2[q0], pa, sj));
+          else HIP_TRY(launch_resblock_chain(rb.c1.data() + q0, rb.c2.data() + q0, seg[g], pa, sj));
+          q0 += seg[g];
+          yin = dst;
+        }
         if (n_side > 0) HIP_TRY(hipEventRecord(m->ev_done[j], sj));
         continue;
       }
