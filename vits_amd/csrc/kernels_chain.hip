@@ -38,7 +38,10 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // Measurement builds (tools/build_variant.sh): -DCHAIN_KO=<bits> removes a part of the kernel to see what the rest
 // costs -- 1: no MFMAs, 2: no weight loads inside the tap loops, 4: operand tiles written without the conversion
-// arithmetic, 8: no fragment reads from LDS.  Results are wrong in such a build; the default build has none of it.
+// arithmetic, 8: no fragment reads from LDS, 16: global loads and stores of NJ consecutive steps a lane (the same bytes in
+// 8- / 16-byte pieces; with 15, the memory skeleton alone: 3.7 -> 5.2 TB/s at 32 channels in bf16, but 4 % on the whole
+// kernel, whose conversion / LDS / MFMA phases take as long as the skeleton).  Results are wrong in such a build; the
+// default build has none of it.
 #ifndef CHAIN_KO
 #define CHAIN_KO 0
 #endif
@@ -136,7 +139,20 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
 
   // the carrier: this wave's rows of its columns, in the accumulator layout, from one round trip to memory
   float xr[WR][NJ][16];
-  {
+  if constexpr (CHAIN_KO & 16) {                            // mock: the same bytes with NJ consecutive steps a lane
+    typedef float fvec __attribute__((ext_vector_type(NJ)));
+    const float* xb = a.x + (long long)b * a.x_bs;
+    int t = t0 - a.R + wn * CW + NJ * l31;
+    t = t >= 0 && t + NJ <= a.L ? t : 0;
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const fvec v = *reinterpret_cast<const fvec*>(xb + (long long)(32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)) * a.x_cs + t);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xr[i][j][r] = v[j];
+      }
+  } else {
     const float* xb = a.x + (long long)b * a.x_bs;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -340,7 +356,24 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
   }
 
   // ---- out = carrier (+ out) on the columns this block owns ----
-  {
+  if constexpr (CHAIN_KO & 16) {
+    typedef float fvec __attribute__((ext_vector_type(NJ)));
+    float* ob = a.out + (long long)b * a.out_bs;
+    const int c = wn * CW + NJ * l31, t = t0 - a.R + c;
+    if (c >= a.R && c + NJ <= W1 - a.R && t + NJ <= a.L) {
+#pragma unroll
+      for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          fvec v;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) v[j] = xr[i][j][r];
+          fvec* dst = reinterpret_cast<fvec*>(ob + (long long)(32 * (wm * WR + i) + 4 * par + (r & 3) + 8 * (r >> 2)) * a.out_cs + t);
+          if (a.accumulate) v += *dst;
+          *dst = v;
+        }
+    }
+  } else {
     float* ob = a.out + (long long)b * a.out_bs;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
