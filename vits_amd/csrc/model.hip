@@ -1013,11 +1013,79 @@ static bool whole_resblocks_enabled() {
   return on;
 }
 
+// How one stage of the generator runs (decided once per call: it depends on batch and length), shared by the workspace
+// query and vits_generator so that the two cannot disagree.
+struct StagePlan {
+  bool stage_x = false, stage_bf16 = false;      // x converted once into the staged f16x2 / bf16 operand format (XG)
+  int nseg[8] = {0};                             // > 0: ResBlock j runs as that many whole-chain / fused-pair launches
+  int seg[8][8];
+  bool fuse_chain[8] = {false};                  // every pair of ResBlock j in one launch each
+  int bufs[8] = {0};                             // work tensors of the stage's size ResBlock j needs (Y, T, YG)
+  int total_bufs = 0;
+};
+
+static StagePlan plan_stage(const vits_model* m, int i, int B, int L) {
+  const vits_config& c = m->cfg;
+  const int nk = c.n_resblock_kernels, nd = c.n_resblock_dilations;
+  const bool single = c.resblock == 2;            // modules.ResBlock2 (reference modules.py:228-252)
+  StagePlan p;
+  // f16x2 arithmetic: every conv of an unfused pair takes its input in the staged operand format (leaky-relu applied,
+  // split into fp16 h / l) -- x is converted once for all chains, and the second conv of a pair writes its result
+  // twice, as fp32 (the residual of the next pair) and staged (the input of the next pair's first conv).
+  // Plain-bf16 arithmetic: the same where the stage's convs run on the LDS-DMA kernel (the one that writes the second
+  // copy), i.e. for rows in 128s at sizes that fill the chip; decided per stage, for every chain at once.
+  for (int j = 0; j < nk && staged_pairs_enabled() && !single; ++j) {
+    const ResBlock& rb = m->rbs[i * nk + j];
+    bool fused = fused_pairs_enabled();
+    for (int q = 0; q < nd && fused; ++q) fused = pair_profitable(rb.c1[q], rb.c2[q]);
+    if (!fused && rb.c1[0].prec == PREC_F16X2 && rb.c2[0].prec == PREC_F16X2) p.stage_x = true;
+  }
+  if (!p.stage_x && staged_pairs_enabled() && !single) {
+    p.stage_bf16 = true;
+    for (int j = 0; j < nk && p.stage_bf16; ++j) {
+      const ResBlock& rb = m->rbs[i * nk + j];
+      for (int q = 0; q < nd && p.stage_bf16; ++q)
+        p.stage_bf16 = conv_takes_glb(rb.c1[q], B, L) && conv_takes_glb(rb.c2[q], B, L);
+    }
+  }
+  for (int j = 0; j < nk; ++j) {
+    const ResBlock& rb = m->rbs[i * nk + j];
+    // One decision per chain: the fused pair ping-pongs between Y and T (its blocks read a halo of their input, so
+    // it cannot run in place) while the two-launch pair keeps T for the tensor between its convs and updates Y in
+    // place; a chain that mixed the two would hand a fused pair's output in T to a two-launch pair that overwrites
+    // T before reading it.  So a chain is fused only when every one of its pairs is.
+    p.fuse_chain[j] = fused_pairs_enabled() && !single;
+    for (int q = 0; q < nd && p.fuse_chain[j]; ++q) p.fuse_chain[j] = pair_profitable(rb.c1[q], rb.c2[q]);
+    p.nseg[j] = whole_resblocks_enabled() && !single && nd <= 8 ? chain_plan(rb.c1.data(), rb.c2.data(), nd, p.seg[j]) : 0;
+    if (p.nseg[j] > 0) p.bufs[j] = p.nseg[j] > 1 ? 2 : 0;       // a whole ResBlock in one launch needs none
+    else if (single || p.fuse_chain[j]) p.bufs[j] = nd > 1 ? 2 : 0;
+    else {
+      const int p1 = rb.c1[0].prec;
+      const bool staged_in = staged_pairs_enabled() && ((p1 == PREC_F16X2 && p.stage_x) || (p1 == PREC_BF16 && p.stage_bf16));
+      p.bufs[j] = staged_in ? 3 : 2;
+    }
+    p.total_bufs += p.bufs[j];
+  }
+  return p;
+}
+
+// floats of the work tensors every ResBlock chain of one stage needs, the largest over the stages
+static int64_t gen_scratch_floats(const vits_model* m, int B, int t_dec) {
+  int64_t L = t_dec, mx = 0;
+  for (int i = 0; i < m->cfg.n_upsamples; ++i) {
+    L *= m->cfg.upsample_rates[i];
+    const int64_t one = pad256((int64_t)(m->cfg.upsample_initial_channel >> (i + 1)) * L * B) / 4;
+    mx = std::max(mx, one * plan_stage(m, i, B, (int)L).total_bufs);
+  }
+  return mx;
+}
+
 int64_t vits_generator_workspace_bytes(const vits_model* m, int B, int t_dec) {
   if (!model_alive(m)) return -1;
-  // x, the sum of the chains, x in staged form; per ResBlock chain: its carrier, the tensor between the two convs of
-  // a pair, the carrier in staged form
-  return (3 + 3 * (int64_t)m->cfg.n_resblock_kernels) * pad256(gen_buf_floats(m, B, t_dec));
+  // x, the sum of the chains, x in staged form (the largest stage's size each); then, sized per stage, what the
+  // ResBlock chains of that stage need: nothing for a ResBlock that runs whole, its carrier and the tensor between the
+  // two convs of a pair otherwise, and the carrier in staged form for unfused pairs
+  return 3 * pad256(gen_buf_floats(m, B, t_dec)) + pad256(gen_scratch_floats(m, B, t_dec));
 }
 
 int vits_generator(const vits_model* m, const float* z, const int* lengths, const float* cond, int B, int T, int t_dec,
@@ -1030,13 +1098,9 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
   Arena ar(ws, ws_bytes);
   const int64_t nbuf = gen_buf_floats(m, B, t_dec);
   float *X = ar.take(nbuf), *XS = ar.take(nbuf), *XG = ar.take(nbuf), *Y[8], *Tt[8], *YG[8];
-  for (int j = 0; j < nk; ++j) {
-    Y[j] = ar.take(nbuf);
-    Tt[j] = ar.take(nbuf);
-    YG[j] = ar.take(nbuf);
-    if (!Y[j] || !Tt[j] || !YG[j]) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
-  }
-  if (!X || !XS || !XG) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
+  const int64_t scratch_floats = gen_scratch_floats(m, B, t_dec);
+  float* scratch = ar.take(scratch_floats);       // the chains' work tensors, carved anew for every stage
+  if (!X || !XS || !XG || !scratch) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
   // per-kernel event timing needs the launches of one step serialised on one stream
   const int n_side = prof_enabled() ? 0 : std::max(0, std::min(m->n_side, m->side_limit));
   RangeFlagScope range_scope(m->range_flag);
@@ -1061,20 +1125,17 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
     // result twice, as fp32 (the residual of the next pair) and staged (the input of the next pair's first conv).
     // Plain-bf16 arithmetic: the same where the stage's convs run on the LDS-DMA kernel (the one that writes the second
     // copy), i.e. for rows in 128s at sizes that fill the chip; decided per stage, for every chain at once.
-    bool stage_x = false, stage_bf16 = false;
+    const StagePlan plan = plan_stage(m, i, B, L);
+    const bool stage_x = plan.stage_x, stage_bf16 = plan.stage_bf16;
     const bool single = c.resblock == 2;            // modules.ResBlock2 (reference modules.py:228-252)
-    for (int j = 0; j < nk && staged_pairs_enabled() && !single; ++j) {
-      const ResBlock& rb = m->rbs[i * nk + j];
-      bool fused = fused_pairs_enabled();
-      for (int q = 0; q < nd && fused; ++q) fused = pair_profitable(rb.c1[q], rb.c2[q]);
-      if (!fused && rb.c1[0].prec == PREC_F16X2 && rb.c2[0].prec == PREC_F16X2) stage_x = true;
-    }
-    if (!stage_x && staged_pairs_enabled() && !single) {
-      stage_bf16 = true;
-      for (int j = 0; j < nk && stage_bf16; ++j) {
-        const ResBlock& rb = m->rbs[i * nk + j];
-        for (int q = 0; q < nd && stage_bf16; ++q)
-          stage_bf16 = conv_takes_glb(rb.c1[q], B, L) && conv_takes_glb(rb.c2[q], B, L);
+    {
+      const int64_t one = pad256((int64_t)(ch0 >> (i + 1)) * L * B) / 4;
+      if (one * plan.total_bufs > scratch_floats) return fail(VITS_ERR_WORKSPACE, "generator: workspace too small");
+      float* next = scratch;
+      for (int j = 0; j < nk; ++j) {
+        Y[j] = Tt[j] = YG[j] = nullptr;
+        if (plan.bufs[j] >= 2) { Y[j] = next; Tt[j] = next + one; next += 2 * one; }
+        if (plan.bufs[j] >= 3) { YG[j] = next; next += one; }
       }
     }
     if (stage_x)
@@ -1093,14 +1154,9 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
                        : (j == nk - 1 ? s : m->side[std::min(j, n_side - 1)]);
       const ResBlock& rb = m->rbs[i * nk + j];
       const float* yin = X;
-      // One decision per chain: the fused pair ping-pongs between Y and T (its blocks read a halo of their input, so
-      // it cannot run in place) while the two-launch pair keeps T for the tensor between its convs and updates Y in
-      // place; a chain that mixed the two would hand a fused pair's output in T to a two-launch pair that overwrites
-      // T before reading it.  So a chain is fused only when every one of its pairs is.
-      bool fuse_chain = fused_pairs_enabled() && !single;
-      for (int q = 0; q < nd && fuse_chain; ++q) fuse_chain = pair_profitable(rb.c1[q], rb.c2[q]);
-      int seg[8];
-      const int nseg = whole_resblocks_enabled() && !single && nd <= 8 ? chain_plan(rb.c1.data(), rb.c2.data(), nd, seg) : 0;
+      const bool fuse_chain = plan.fuse_chain[j];
+      const int nseg = plan.nseg[j];
+      const int* seg = plan.seg[j];
       if (nseg > 0) {
         // the ResBlock in nseg launches (one: x is read once and the result goes straight into the stage's sum); the
         // carrier between two segments takes turns in Y and T
