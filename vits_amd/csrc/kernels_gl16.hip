@@ -165,6 +165,9 @@ __device__ __forceinline__ void epilogue16(const ConvArgs& a, f32x4 (&acc)[4][NT
           if (flags & F_ACCUM) e += ov[jp][r];
           if (flags & F_MASK_POST) e *= m;
           v[r] = e;
+#if defined(GL16_KO) && (GL16_KO & 2)
+          if (a.L < 0)
+#endif
           out_b[(long long)(r0 + r) * a.out_cs + t] = e;
         }
       }
@@ -178,8 +181,13 @@ __device__ __forceinline__ void epilogue16(const ConvArgs& a, f32x4 (&acc)[4][NT
         report_range(a.range_flag, amax);
         uint4 oh, ol;
         split_f16x2(v, oh, ol);
-        stg_b[unit0 + t] = oh;
-        stg_b[unit0 + a.L + t] = ol;
+#if defined(GL16_KO) && (GL16_KO & 2)
+        if (a.L < 0 || (oh.x ^ ol.y) == 0x12345678u)
+#endif
+        {
+          stg_b[unit0 + t] = oh;
+          stg_b[unit0 + a.L + t] = ol;
+        }
       }
     }
   }
@@ -193,8 +201,17 @@ __device__ unsigned long long* g_gl16_stamps = nullptr;      // [slots][2]: shad
 __device__ unsigned long long g_gl16_stamp_slots = 0;
 #endif
 
+#ifdef GL16_TIMELINE
+__device__ unsigned long long* g_gl16_timeline = nullptr;    // [slots][6]: 100 MHz ticks at block entry, loop start, loop end,
+__device__ unsigned long long g_gl16_timeline_slots = 0;     // block end; HW_ID; XCC_ID
+#endif
+
 template <int WN, int WGM, int WGN, int K, int S>
 __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
+#ifdef GL16_TIMELINE
+  // Diagnostic build only (tools/build_variant.sh timeline kernels_gl16.hip -DGL16_TIMELINE): where a block's time goes.
+  const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int SUBN = WN == 2 ? 2 : 1;          // 16-column tiles per sub-step (the wider wave tiles have 96 / 128
                                                  // accumulator registers: two sets of four activation fragments would spill)
   constexpr int NSUB = 2 * WN / SUBN;            // sub-steps per pair step
@@ -371,6 +388,9 @@ __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
   // buffer of their own that nothing else reads; no output depends on them.
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef GL16_TIMELINE
+  const unsigned long long tl_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int slot_rd = 0;                               // ring slot of flat step 2p (even); the slots of p - 1 are written
   int p = 0;                                     // pair step
   for (int c0 = 0; c0 < nchunks; c0 += 4) {
@@ -448,10 +468,34 @@ __global__ __launch_bounds__(256, 2) void conv_gl16_kernel(const ConvArgs a) {
     }
   }
 #endif
+#ifdef GL16_TIMELINE
+  const unsigned long long tl_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
   // nothing of this block may still be on its way into LDS when the block's LDS is handed to the next one
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+#if defined(GL16_KO) && (GL16_KO & 1)
+  if (a.L < 0)                                   // knock-out (measurement only): no epilogue at all
+#endif
   epilogue16<NT>(a, acc, (mt0 + wm * 2) * 32, t0 + wn * 32 * WN, lane, b);
+#ifdef GL16_TIMELINE
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the epilogue's stores have been accepted
+    const unsigned long long tl_end = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* sb = g_gl16_timeline;
+    if (sb && threadIdx.x == 0) {
+      const unsigned long long blk = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z);
+      if (blk < g_gl16_timeline_slots) {
+        sb[6 * blk] = tl_entry;
+        sb[6 * blk + 1] = tl_loop0;
+        sb[6 * blk + 2] = tl_loop1;
+        sb[6 * blk + 3] = tl_end;
+        sb[6 * blk + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+        sb[6 * blk + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+      }
+    }
+  }
+#endif
 }
 
 namespace {
@@ -521,6 +565,16 @@ hipError_t launch_conv_gl16(ConvArgs& a, int bn, hipStream_t stream) {
 }
 
 }  // namespace vits
+
+#ifdef GL16_TIMELINE
+// Diagnostic build only: where the timeline goes (a device buffer of 6 * slots 64-bit words the caller owns).
+extern "C" int vits_debug_gl16_timeline_buffer(void* buf, unsigned long long slots) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(vits::g_gl16_timeline), &p, sizeof p) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(vits::g_gl16_timeline_slots), &slots, sizeof slots) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 #ifdef GL16_STAMP
 // Diagnostic build only: where the stamps go (a device buffer of 2 * slots 64-bit words the caller owns).
