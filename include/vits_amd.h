@@ -213,6 +213,14 @@ int vits_op_conv1d(const void* packed_w, const float* bias_rows, int cin, int ro
                    int precision, const float* x, int B, int L, const int* lengths, const float* cbias,
                    const float* in_cbias, const float* res, float* out, int flags, float in_scale, float in_slope,
                    void* stream);
+/* vits_op_conv1d without masks and per-batch biases, with a second copy of the result in the staged operand format
+ * (leaky-relu(out_slope) applied, then converted) in out2: what the generator's stages hand to the ResBlock convs
+ * (reference models.py:290-298: x = ups[i](x), then every ResBlock starts with leaky_relu(x, 0.1)).  Precision 2 / 3
+ * only; plain convs with flag 512 (staged input), and the x8 / x4 transposed convs (mode 2 / 3), whose out2 covers the
+ * L * 8 or L * 4 output steps.  out2 may be NULL (then this is vits_op_conv1d). */
+int vits_op_conv1d_out2(const void* packed_w, const float* bias_rows, int cin, int rows, int taps, int dilation, int mode,
+                        int precision, const float* x, int B, int L, const float* res, float* out, float* out2, int flags,
+                        float in_scale, float in_slope, float out_slope, void* stream);
 /* One ResBlock1 pair (reference modules.py:206-219, one iteration of its loop) in a single launch:
  * out = x + conv2(lrelu(conv1(lrelu(x)))) (+ out when accumulate), conv1 dilated, conv2 dilation 1, both with `taps`
  * taps (3, 5, 7, 9 or 11; (taps - 1) / 2 * dilation <= 25) and f16x2-packed weights [C][C][taps]; C = 32 or 64;

@@ -165,6 +165,64 @@ def test_conv_transpose(N, prec, u, k, cin, cout, L):
     assert (got - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("pname", ["bf16", "f16x2"])
+@pytest.mark.parametrize("u,k,cin,cout,L,B", [(8, 16, 512, 256, 258, 2), (8, 16, 256, 128, 1500, 2), (4, 4, 128, 64, 700, 3),
+                                              (8, 16, 64, 32, 33, 1), (4, 4, 64, 16, 1, 2)])
+def test_conv_transpose_writes_the_staged_copy(N, pname, u, k, cin, cout, L, B):
+    """The x8 / x4 transposed convs of the generator also write their result in the staged operand format of the
+    ResBlock convs that read it (leaky-relu(0.1), then bf16 or the fp16 h / l split): the fp32 result must be the
+    bytes of the launch without the copy, and the copy must decode to exactly the converted fp32 result."""
+    from vits_amd import weights
+    p = PREC[pname]
+    g = torch.Generator().manual_seed(u * 1000 + L + cin)
+    wt = torch.randn(cin, cout, k, generator=g) / math.sqrt(cin * k / u)
+    b = torch.randn(cout, generator=g)
+    x = torch.randn(B, cin, L, generator=g)
+    w_rows, b_rows, mode, taps = weights.transposed_conv_rows(wt, b, u, k, (k - u) // 2)
+    pk, bd, xd = dev(weights.pack_rows(w_rows, p)), dev(b_rows), dev(x)
+    stream = torch.cuda.current_stream().cuda_stream
+    Lo = L * u
+    plain = torch.full((B, cout, Lo), float("nan"), device="cuda")
+    both = torch.full((B, cout, Lo), float("nan"), device="cuda")
+    staged = torch.full((B, cout, Lo), float("nan"), device="cuda")        # an fp32-sized buffer is always enough
+
+    def run(out, out2):
+        N.check(N.lib.vits_op_conv1d_out2(pk.data_ptr(), bd.data_ptr(), cin, cout * u, taps, 1, mode, p, xd.data_ptr(), B, L,
+                                          0, out.data_ptr(), N.ptr(out2), N.F_IN_LRELU, 1.0 / 3, 0.1, 0.1, stream), "op_conv1d_out2")
+    run(plain, None)
+    run(both, staged)
+    torch.cuda.synchronize()
+    assert torch.equal(both, plain)
+    act = F.leaky_relu(plain, 0.1).cpu()
+    flat = staged.reshape(-1).cpu()
+    if pname == "bf16":
+        got = flat[:B * cout * Lo // 2].contiguous().view(torch.bfloat16).reshape(B, cout // 8, Lo, 8)
+        assert torch.equal(got.permute(0, 1, 3, 2).reshape(B, cout, Lo).float(), act.to(torch.bfloat16).float())
+    else:
+        got = flat.contiguous().view(torch.float16).reshape(B, cout // 8, 2, Lo, 8)
+        h = got[:, :, 0].permute(0, 1, 3, 2).reshape(B, cout, Lo).float()
+        lo = got[:, :, 1].permute(0, 1, 3, 2).reshape(B, cout, Lo).float()
+        assert torch.equal(h, act.to(torch.float16).float())
+        assert torch.equal(lo, (act - h).to(torch.float16).float())
+
+
+def test_conv_out2_is_refused_where_no_kernel_writes_it(N):
+    """A second copy is asked of a conv no kernel writes one for (x2 transposed conv, fp32 arithmetic): an error, not a
+    silently missing tensor."""
+    from vits_amd import weights
+    g = torch.Generator().manual_seed(5)
+    stream = torch.cuda.current_stream().cuda_stream
+    wt = torch.randn(64, 32, 4, generator=g)
+    w_rows, b_rows, mode, taps = weights.transposed_conv_rows(wt, torch.zeros(32), 2, 4, 1)
+    x = torch.randn(1, 64, 100, device="cuda")
+    out, out2 = torch.empty(1, 32, 200, device="cuda"), torch.empty(1, 32, 200, device="cuda")
+    for p, w, md, rows, tp in ((PREC["f16x2"], w_rows, mode, 64, taps), (PREC["fp32"], torch.randn(64, 64, 3, generator=g), 0, 64, 3)):
+        pk = dev(weights.pack_rows(w, p))
+        rc = N.lib.vits_op_conv1d_out2(pk.data_ptr(), 0, 64, rows, tp, 1, md, p, x.data_ptr(), 1, 100, 0, out.data_ptr(),
+                                       out2.data_ptr(), 0, 1.0, 1.0, 0.1, stream)
+        assert rc != 0
+
+
 @pytest.mark.parametrize("pname,bound", [("fp32", 2e-6), ("bf16x3", 2e-6), ("f16x2", 2e-6)])
 def test_conv_split_schemes_over_a_wide_dynamic_range(N, pname, bound):
     """The operand splits must hold their relative accuracy for small and large values alike (fp16 subnormals carry

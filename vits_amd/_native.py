@@ -87,6 +87,7 @@ def _load():
                                     C.POINTER(C.c_int64)]),
         "vits_op_set_range_flag": (None, [vp]),
         "vits_op_conv1d": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, f32, f32, vp]),
+        "vits_op_conv1d_out2": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, i32, f32, f32, f32, vp]),
         "vits_op_resblock_pair": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, C.c_float, vp]),
         "vits_op_resblock_pair_prec": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, C.c_float, vp]),
         "vits_op_resblock_chain": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, i32, C.c_float, vp]),

@@ -386,6 +386,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
   } else if constexpr (MODE == MODE_UP8 || MODE == MODE_UP4) {
     // rows of an m-tile: 8*g + 4*par + jj  ->  channel = cb*8 + 2*g + par, phase = jj (+4 for the second class)
     constexpr int UP = MODE == MODE_UP8 ? 8 : 4;
+    constexpr bool OUT2 = (EXTRA & (EPI_OUT2 | EPI_OUT2B)) != 0;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       if (!mt_ok[i]) continue;
@@ -399,14 +400,61 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
         const int t = t0 + (wn * WN + j) * 32 + l31;
         if (t >= a.L) continue;
         const unsigned lo_out = (unsigned)(par * a.out_cs + UP * t + ph0);
+        float v[4][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float4 v;
-          v.x = acc[i][j][4 * g + 0] + bz[g];
-          v.y = acc[i][j][4 * g + 1] + bz[g];
-          v.z = acc[i][j][4 * g + 2] + bz[g];
-          v.w = acc[i][j][4 * g + 3] + bz[g];
-          *reinterpret_cast<float4*>(out_b + (long long)(cb * 8 + 2 * g) * a.out_cs + lo_out) = v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[g][q] = acc[i][j][4 * g + q] + bz[g];
+          *reinterpret_cast<float4*>(out_b + (long long)(cb * 8 + 2 * g) * a.out_cs + lo_out) =
+              make_float4(v[g][0], v[g][1], v[g][2], v[g][3]);
+        }
+        if constexpr (OUT2) {
+          // A second copy in the staged operand format of the convs that read this tensor (leaky-relu(out_slope)
+          // applied): a 16-byte unit is eight consecutive channels of one time step, and a lane holds four phases of
+          // every other channel.  Lanes l and l + 32 (even and odd channels of the same steps) trade two phases each:
+          // afterwards lane l has all eight channels of phases 0, 1 and lane l + 32 those of phases 2, 3.
+          if (a.out2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              // (the wait states stand in for the hazard checks the compiler does not make inside an asm statement)
+              asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v[g][0]), "+v"(v[g][2]));
+              asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v[g][1]), "+v"(v[g][3]));
+            }
+            const long long Lo = (long long)a.L * UP;
+            uint4* sb = reinterpret_cast<uint4*>(a.out2 + (long long)b * a.out2_bs);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const long long to = (long long)UP * t + ph0 + 2 * par + u;
+              float c8[8];
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                c8[2 * g] = fmaxf(v[g][u], v[g][u] * a.out_slope);
+                c8[2 * g + 1] = fmaxf(v[g][2 + u], v[g][2 + u] * a.out_slope);
+              }
+              if constexpr ((EXTRA & EPI_OUT2) != 0) {
+                unsigned h4[4], l4[4];
+                float amax = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  amax = fmaxf(amax, fmaxf(fabsf(c8[2 * q]), fabsf(c8[2 * q + 1])));
+                  f32x2 e = {fminf(fmaxf(c8[2 * q], -65504.f), 65504.f), fminf(fmaxf(c8[2 * q + 1], -65504.f), 65504.f)};
+                  const f16x2 h = __builtin_convertvector(e, f16x2);
+                  const f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, f32x2), f16x2);
+                  h4[q] = __builtin_bit_cast(unsigned, h);
+                  l4[q] = __builtin_bit_cast(unsigned, l);
+                }
+                report_f16_range(a.range_flag, amax);
+                sb[(long long)cb * 2 * Lo + to] = make_uint4(h4[0], h4[1], h4[2], h4[3]);
+                sb[((long long)cb * 2 + 1) * Lo + to] = make_uint4(l4[0], l4[1], l4[2], l4[3]);
+              } else {
+                unsigned o4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  o4[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{c8[2 * q], c8[2 * q + 1]}, bf16x2));
+                sb[(long long)cb * Lo + to] = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+              }
+            }
+          }
         }
       }
     }
@@ -1094,7 +1142,7 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
       return;
     }
   }
-  conv_epilogue<WM, WN, MODE, true>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+  conv_epilogue<WM, WN, MODE, true, (MODE == MODE_UP8 || MODE == MODE_UP4) ? EPI_OUT2B : 0>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1365,7 +1413,7 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
       return;
     }
   }
-  conv_epilogue<WM, WN, MODE, true, STG ? EPI_OUT2 : 0>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+  conv_epilogue<WM, WN, MODE, true, (STG || MODE == MODE_UP8 || MODE == MODE_UP4) ? EPI_OUT2 : 0>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2011,7 +2059,8 @@ static hipError_t launch_b1(ConvArgs& a, hipStream_t stream) {
     hipError_t err = hipSuccess;
     if (try_launch_glb(a, stream, err)) return err;
   }
-  if (a.out2) return hipErrorInvalidValue;      // only the LDS-DMA kernel writes the second copy (see conv_takes_glb)
+  // of the plain convs only the LDS-DMA kernel writes the second copy (see conv_takes_glb)
+  if (a.out2 && MODE != MODE_UP8 && MODE != MODE_UP4) return hipErrorInvalidValue;
   constexpr int BN = 32 * WN * WGN;
   a.width = BN + (a.width);
   a.rs = a.width;                    // columns per half slab
@@ -2609,8 +2658,11 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   if (a.split_row && (d.mode != MODE_PLAIN || a.split_row % 64 || a.split_row >= M || !a.out_hi || a.out2 ||
                       (a.flags & (F_OUT_STAGED | F_IN_STAGED)) || ((a.flags | a.flags_hi) & F_RES_SUB)))
     return hipErrorInvalidValue;
-  if (a.out2 && (d.mode != MODE_PLAIN || (p != PREC_F16X2 && p != PREC_BF16) || (a.flags & F_OUT_STAGED) || !(a.flags & F_IN_STAGED)))
-    return hipErrorInvalidValue;                       // the staged-input f16x2 kernels write it
+  // a second, staged copy of the result: the staged-input f16x2 / bf16 kernels write it, and the x8 / x4 transposed convs
+  const bool up84 = d.mode == MODE_UP8 || d.mode == MODE_UP4;
+  if (a.out2 && ((p != PREC_F16X2 && p != PREC_BF16) || (a.flags & F_OUT_STAGED) ||
+                 !(up84 || (d.mode == MODE_PLAIN && (a.flags & F_IN_STAGED)))))
+    return hipErrorInvalidValue;
   if (a.split_row && p != PREC_F32 && p != PREC_BF16X3) return hipErrorInvalidValue;       // the kernels that run the flow
   // deferred LayerNorm: the bf16x3 kernels' 64-row wave tiles only; statistics are per 64-channel unit
   if (a.ln_in_stats || a.ln_res_stats || a.ln_out_stats) {

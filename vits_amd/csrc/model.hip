@@ -204,7 +204,7 @@ ConvArgs conv_simple_args(const ConvDesc& d, const float* x, float* out, int B, 
                           const float* in_cbias = nullptr, int in_cbias_bs = 0, float in_scale = 1.f, float in_slope = 1.f,
                           float out_slope = 1.f, float* out2 = nullptr) {
   ConvArgs a = base_args(x, (long long)d.Cin * L, L, out, (long long)d.cout * L * d.up, L * d.up, B, L, lengths, flags);
-  a.out2 = out2; a.out2_bs = staged_row_floats(d.prec, d.cout, L);   // staged copy: f16x2 as many bytes as fp32, bf16 half
+  a.out2 = out2; a.out2_bs = staged_row_floats(d.prec, d.cout, L * d.up);   // staged copy: f16x2 as many bytes as fp32, bf16 half
   if (flags & F_IN_STAGED) a.x_bs = staged_row_floats(d.prec, d.Cin, L);
   if (flags & F_OUT_STAGED) a.out_bs = staged_row_floats(d.prec, d.cout, L);
   a.out_slope = out_slope;
@@ -1032,6 +1032,16 @@ static bool whole_resblocks_enabled() {
   return on;
 }
 
+// VITS_GEN_UPS_STAGE=0: the staged copy of a stage's input comes from the conversion kernel, not from the transposed
+// conv's epilogue (measurement knob).
+static bool ups_stage_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VITS_GEN_UPS_STAGE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 // How one stage of the generator runs (decided once per call: it depends on batch and length), shared by the workspace
 // query and vits_generator so that the two cannot disagree.
 struct StagePlan {
@@ -1133,8 +1143,14 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
   float in_scale = 1.f;
   int L = t_dec;
   for (int i = 0; i < c.n_upsamples; ++i) {
-    // x = ups[i](leaky_relu(x, 0.1)); the division by num_kernels of the previous stage rides on the input scale
-    TRY(conv_simple(m->ups[i], XS, X, B, L, nullptr, F_IN_LRELU, s, nullptr, nullptr, 0, nullptr, 0, in_scale, 0.1f));
+    // x = ups[i](leaky_relu(x, 0.1)); the division by num_kernels of the previous stage rides on the input scale.
+    // Where the stage's ResBlocks read x in the staged operand format, the x8 / x4 transposed convs write that copy
+    // themselves (same values as the conversion kernel: leaky-relu(0.1) of the fp32 result, then the split).
+    const StagePlan plan = plan_stage(m, i, B, L * c.upsample_rates[i]);
+    const bool ups_stages = ups_stage_enabled() && (m->ups[i].mode == MODE_UP8 || m->ups[i].mode == MODE_UP4) &&
+                            ((plan.stage_x && m->ups[i].prec == PREC_F16X2) || (plan.stage_bf16 && m->ups[i].prec == PREC_BF16));
+    TRY(conv_simple(m->ups[i], XS, X, B, L, nullptr, F_IN_LRELU, s, nullptr, nullptr, 0, nullptr, 0, in_scale, 0.1f, 0.1f,
+                    ups_stages ? XG : nullptr));
     L *= c.upsample_rates[i];
     // The nk ResBlocks read the same x and are independent until their outputs are summed (models.py:292-298):
     // chain j runs on its own stream; its last conv accumulates into XS after chain j-1's has (same order of
@@ -1144,7 +1160,6 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
     // result twice, as fp32 (the residual of the next pair) and staged (the input of the next pair's first conv).
     // Plain-bf16 arithmetic: the same where the stage's convs run on the LDS-DMA kernel (the one that writes the second
     // copy), i.e. for rows in 128s at sizes that fill the chip; decided per stage, for every chain at once.
-    const StagePlan plan = plan_stage(m, i, B, L);
     const bool stage_x = plan.stage_x, stage_bf16 = plan.stage_bf16;
     const bool single = c.resblock == 2;            // modules.ResBlock2 (reference modules.py:228-252)
     {
@@ -1157,9 +1172,9 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
         if (plan.bufs[j] >= 3) { YG[j] = next; next += one; }
       }
     }
-    if (stage_x)
+    if (stage_x && !ups_stages)
       HIP_TRY(launch_stage_f16x2(X, XG, B, m->rbs[i * nk].c1[0].Cin, L, 1.f, 0.1f, g_range_flag, s));
-    if (stage_bf16)
+    if (stage_bf16 && !ups_stages)
       HIP_TRY(launch_stage_bf16(X, XG, B, m->rbs[i * nk].c1[0].Cin, L, 1.f, 0.1f, s));
     if (n_side > 0) {
       HIP_TRY(hipEventRecord(m->ev_fork, s));
@@ -1287,6 +1302,15 @@ int vits_op_conv1d(const void* w, const float* bias, int cin, int rows, int taps
   TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode, precision));
   return conv_simple(d, x, out, B, L, lengths, flags, (hipStream_t)stream, res, cbias, rows, in_cbias, cin, in_scale,
                      in_slope, in_slope);
+}
+
+int vits_op_conv1d_out2(const void* w, const float* bias, int cin, int rows, int taps, int dilation, int mode, int precision,
+                        const float* x, int B, int L, const float* res, float* out, float* out2, int flags, float in_scale,
+                        float in_slope, float out_slope, void* stream) {
+  ConvDesc d;
+  TRY(make_desc(d, w, bias, cin, rows, taps, dilation, mode, precision));
+  return conv_simple(d, x, out, B, L, nullptr, flags, (hipStream_t)stream, res, nullptr, 0, nullptr, 0, in_scale, in_slope,
+                     out_slope, out2);
 }
 
 int vits_op_resblock_pair(const void* w1, const float* b1, const void* w2, const float* b2, int channels, int taps,
