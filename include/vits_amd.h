@@ -247,6 +247,12 @@ int vits_op_layer_norm(const float* x, float* y, const float* gamma, const float
                        int L, int mask_out, void* stream);
 int vits_op_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out, int B,
                       int H, int DK, int L, int window, void* stream);
+/* The same with the arithmetic of the matrix-core kernel (rows of 256 steps and more) chosen: precision 1 = three bf16
+ * terms per operand (what vits_op_attention runs), 3 = fp16 h + l, what the frame-rate encoder runs beside its f16x2
+ * convs (reference attentions.py:216-257 at frame rate, frame_prior_network.py).  Shorter rows run on the vector-ALU
+ * kernel in fp32 either way. */
+int vits_op_attention_prec(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out, int B,
+                           int H, int DK, int L, int window, int precision, void* stream);
 
 #ifdef __cplusplus
 }

@@ -645,8 +645,8 @@ def reference_attention(q, k, v, ek, ev, lengths, H, W=4):
                                  (1400, 2), (256, 70), (258, 64), (300, 33), (511, 17)])
 def test_attention(N, L, B):
     """Short rows and small grids: the lanes-on-keys kernel; L >= 512, and L >= 256 when the batch fills the chip with
-    64-query blocks: the matrix-core kernel (bf16x3 products, two passes over the keys; 64- and 128-query blocks).
-    Both against the reference's own formulation (padded relative embeddings, skew reshapes)."""
+    64-query blocks: the matrix-core kernel (bf16x3 products, one pass over the keys with a running maximum; 64- and
+    128-query blocks).  Both against the reference's own formulation (padded relative embeddings, skew reshapes)."""
     g = torch.Generator().manual_seed(L)
     H, dk = 2, 96
     C = H * dk
@@ -660,3 +660,49 @@ def test_attention(N, L, B):
                                     out.data_ptr(), B, H, dk, L, 4, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("L,B", [(600, 2), (861, 3), (1400, 2), (256, 70), (258, 64), (511, 17), (2500, 1)])
+def test_attention_matrix_core_kernel_in_f16x2(N, L, B):
+    """The matrix-core attention with its operands split into fp16 h + l (what the frame-rate encoder runs beside its
+    f16x2 convs): the same reference, the same fp32-grade tolerance; and a whole row of masked queries (uniform
+    attention, reference attentions.py:240-243 with masked_fill(-1e4)) is reproduced too."""
+    g = torch.Generator().manual_seed(L + 1)
+    H, dk = 2, 96
+    C = H * dk
+    qkv = torch.randn(B, 3 * C, L, generator=g) * 1.5
+    ek, ev = torch.randn(9, dk, generator=g) * 0.1, torch.randn(9, dk, generator=g) * 0.1
+    lengths = torch.tensor([L, max(1, (2 * L) // 3)] + [max(1, L - 7 * i) for i in range(B - 2)], dtype=torch.int32)[:B]
+    ref = reference_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ek, ev, lengths, H)
+    out = torch.empty(B, C, L, device="cuda")
+    qd, kd, vd, ld = dev(qkv), dev(ek), dev(ev), dev(lengths)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    N.lib.vits_op_set_range_flag(flag.data_ptr())
+    try:
+        N.check(N.lib.vits_op_attention_prec(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ld.data_ptr(), out.data_ptr(), B, H,
+                                             dk, L, 4, PREC["f16x2"], torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+    finally:
+        N.lib.vits_op_set_range_flag(0)
+    assert int(flag.cpu()) == 0
+    assert (out.cpu() - ref).abs().max() < 2e-5
+
+
+def test_attention_f16x2_reports_operands_beyond_the_fp16_range(N):
+    g = torch.Generator().manual_seed(3)
+    H, dk, L, B = 2, 96, 600, 1
+    C = H * dk
+    qkv = torch.randn(B, 3 * C, L, generator=g)
+    qkv[0, 2 * C + 5, 17] = 1e5                       # one value of v beyond 65504
+    ek, ev = torch.zeros(9, dk), torch.zeros(9, dk)
+    out = torch.empty(B, C, L, device="cuda")
+    qd, kd, vd = dev(qkv), dev(ek), dev(ev)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    N.lib.vits_op_set_range_flag(flag.data_ptr())
+    try:
+        N.check(N.lib.vits_op_attention_prec(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), 0, out.data_ptr(), B, H, dk, L, 4,
+                                             PREC["f16x2"], torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+    finally:
+        N.lib.vits_op_set_range_flag(0)
+    assert int(flag.cpu()) == 1

@@ -93,6 +93,7 @@ def _load():
         "vits_op_resblock_chain": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, i32, C.c_float, vp]),
         "vits_op_layer_norm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "vits_op_attention": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        "vits_op_attention_prec": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError here means the library does not match include/vits_amd.h

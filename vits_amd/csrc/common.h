@@ -232,8 +232,11 @@ hipError_t launch_conv_gl16(ConvArgs& a, int bn, hipStream_t stream);   // bn = 
 // ---------------------------------------------------------------------------------------------------------
 hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta, const int* lengths,
                              int B, int C, int L, bool mask_out, hipStream_t s);
+// f16x2: the matrix-core kernel (long sequences) splits its operands into fp16 h + l (three products) instead of three
+// bf16 terms (six); range_flag: where it reports an operand beyond the fp16 range (clamped), or null
 hipError_t launch_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
-                            int B, int H, int DK, int L, int window, hipStream_t s);
+                            int B, int H, int DK, int L, int window, hipStream_t s, bool f16x2 = false,
+                            int* range_flag = nullptr);
 hipError_t launch_embed(const int64_t* ids, const float* table, const int* lengths, float* x, int B, int P, int C,
                         int n_vocab, int* err_flag, hipStream_t s);
 hipError_t launch_cond_gemv(const float* emb_g, const int64_t* sid, const float* w, const float* bias, float* out,

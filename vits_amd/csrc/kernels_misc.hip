@@ -263,21 +263,25 @@ static void attention_launch(const float* qkv, const float* emb_k, const float* 
 
 // ---------------------------------------------------------------------------------------------------------
 // The same attention on the matrix cores, for long sequences (L >= 256).
-//   S'[j][i] = k_j . q_i  (keys x queries: the transposed score tile), v_mfma_f32_32x32x16_bf16 with every fp32 operand
-//   split exactly into three bf16 terms and the six largest cross products (fp32-grade, as the bf16x3 convs);
+//   S'[j][i] = k_j . q_i  (keys x queries: the transposed score tile) on v_mfma_f32_32x32x16 with every fp32 operand
+//   split into NP terms:  NP = 3: three bf16 terms (exact) and the six largest cross products, as the bf16x3 convs;
+//                         NP = 2: fp16 h + l (22 bits, clamped to the fp16 range) and three products, as the f16x2 convs;
 //   O[c][i]  = sum_j v[c][j] p[j][i]: the 32 x 32 accumulator layout of S' (a lane holds one query column and, per
 //   register, keys 8g + 4*par + q) is used as the B operand of this product as it stands -- the sum over keys does not
 //   care in which order its terms sit in the MFMA's k slots, so V is staged in that same key order instead of the
 //   probabilities being shuffled across lanes.
 // A block of NW waves owns 32 * NW queries of one (batch, head); keys and values pass through LDS in tiles of 64,
-// split into bf16 planes once per block.  Two passes over the keys: the row maximum first, then exp, row sum and p . v
-// (no rescaling of partial results).  The +-4 relative-position terms: q . Ek through one more MFMA tile (the nine
-// embeddings as nine "keys"), added to the scores inside the band; the band's probabilities are collected per query
-// and multiplied with Ev as one last k step of the p . v product.
+// split into planes once per block.  One pass over the keys with a running row maximum: a lane's registers of O all
+// belong to its own query, so when a tile raises the maximum the partial sums are rescaled by one factor per lane
+// (exp(old - new)) -- the scores are computed once.  The +-4 relative-position terms: q . Ek through one more MFMA tile
+// (the nine embeddings as nine "keys"), added to the scores inside the band; the band's scores are kept per query,
+// turned into probabilities against the final maximum and multiplied with Ev as one last k step of the p . v product.
 // ---------------------------------------------------------------------------------------------------------
 typedef float att_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 att_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 att_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 att_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 att_f16x2 __attribute__((ext_vector_type(2)));
 
 // (v0, v1) -> packed bf16 pairs h, m, l with v = h + m + l exactly (low half = v0)
 __device__ __forceinline__ void att_split3(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
@@ -289,49 +293,70 @@ __device__ __forceinline__ void att_split3(float v0, float v1, unsigned& h, unsi
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, att_bf16x2));
 }
 
-// eight fp32 values -> one 16-byte unit per plane
-__device__ __forceinline__ void att_split3_unit(const float (&v)[8], uint4& h, uint4& m, uint4& l) {
-  unsigned ph[4], pm[4], pl[4];
+// eight fp32 values -> one 16-byte unit per plane; NP = 2: amax collects the largest magnitude seen (range report)
+template <int NP>
+__device__ __forceinline__ void att_split_unit(const float (&v)[8], uint4 (&pl)[NP], float& amax) {
+  unsigned w[NP][4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) att_split3(v[2 * e], v[2 * e + 1], ph[e], pm[e], pl[e]);
-  h = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-  m = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-  l = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+  for (int e = 0; e < 4; ++e) {
+    if constexpr (NP == 3) {
+      att_split3(v[2 * e], v[2 * e + 1], w[0][e], w[1][e], w[2][e]);
+    } else {
+      amax = fmaxf(amax, fmaxf(fabsf(v[2 * e]), fabsf(v[2 * e + 1])));
+      const att_f32x2 c = {fminf(fmaxf(v[2 * e], -65504.f), 65504.f), fminf(fmaxf(v[2 * e + 1], -65504.f), 65504.f)};
+      const att_f16x2 h = __builtin_convertvector(c, att_f16x2);
+      const att_f16x2 l = __builtin_convertvector(c - __builtin_convertvector(h, att_f32x2), att_f16x2);
+      w[0][e] = __builtin_bit_cast(unsigned, h);
+      w[1][e] = __builtin_bit_cast(unsigned, l);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) pl[p] = make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
 }
 
-__device__ __forceinline__ att_f32x16 att_mma(const uint4& a, const uint4& b, att_f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a), __builtin_bit_cast(att_bf16x8, b), c, 0,
-                                                 0, 0);
-}
-
-// six cross products of two three-plane operands, smallest first: a_h b_l, a_h b_m, a_m b_m, a_l b_h, a_m b_h, a_h b_h
-__device__ __forceinline__ att_f32x16 att_mma6(const uint4 (&a)[3], const uint4 (&b)[3], att_f32x16 c) {
-  c = att_mma(a[0], b[2], c);
-  c = att_mma(a[2], b[0], c);
-  c = att_mma(a[1], b[1], c);
-  c = att_mma(a[0], b[1], c);
-  c = att_mma(a[1], b[0], c);
-  c = att_mma(a[0], b[0], c);
+// the cross products of two split operands, smallest first.  Three planes: a_h b_l, a_l b_h, a_m b_m, a_h b_m, a_m b_h,
+// a_h b_h; two planes: a_h b_l, a_l b_h, a_h b_h
+template <int NP>
+__device__ __forceinline__ att_f32x16 att_mma_split(const uint4 (&a)[NP], const uint4 (&b)[NP], att_f32x16 c) {
+  if constexpr (NP == 3) {
+    auto mm = [&](const uint4& x, const uint4& y) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, x), __builtin_bit_cast(att_bf16x8, y), c, 0, 0, 0);
+    };
+    mm(a[0], b[2]);
+    mm(a[2], b[0]);
+    mm(a[1], b[1]);
+    mm(a[0], b[1]);
+    mm(a[1], b[0]);
+    mm(a[0], b[0]);
+  } else {
+    auto mm = [&](const uint4& x, const uint4& y) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(att_f16x8, x), __builtin_bit_cast(att_f16x8, y), c, 0, 0, 0);
+    };
+    mm(a[0], b[1]);
+    mm(a[1], b[0]);
+    mm(a[0], b[0]);
+  }
   return c;
 }
 
 constexpr int ATT_KT = 64;                         // keys per LDS tile
 constexpr int ATT_NCG = ATT_DK / 8;                // 16-byte channel groups per head (12)
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ ek,
+template <int NW, int NP>
+__global__ __launch_bounds__(64 * NW, 2) void attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ ek,
                                                                   const float* __restrict__ ev,
                                                                   const int* __restrict__ lengths, float* __restrict__ out,
-                                                                  int H, int L) {
+                                                                  int H, int L, int* range_flag) {
   constexpr int DK = ATT_DK, W = ATT_W, NR = 2 * ATT_W + 1, NQ = 32 * NW, NT = 64 * NW, NCG = ATT_NCG;
-  constexpr int KQ_UNITS = 3 * NCG * ATT_KT;       // K tile: [3 planes][12 groups][64 keys]
-  constexpr int VQ_UNITS = 3 * DK * 8;             // V tile: [3 planes][96 channels][4 k steps x 2 halves], keys permuted
+  constexpr int KQ_UNITS = NP * NCG * ATT_KT;      // K tile: [NP planes][12 groups][64 keys]
+  constexpr int VQ_UNITS = NP * DK * 8;            // V tile: [NP planes][96 channels][4 k steps x 2 halves], keys permuted
+  static_assert(NP * NCG * NQ <= KQ_UNITS + VQ_UNITS, "the Q staging area fits the K / V tile space");
   extern __shared__ __attribute__((aligned(16))) uint4 att_m[];
   uint4* kq = att_m;
   uint4* vq = att_m + KQ_UNITS;
-  uint4* evq = vq + VQ_UNITS;                      // Ev as one k step of V: [3 planes][96 channels][2 halves]
-  float* qe_s = reinterpret_cast<float*>(evq + 3 * DK * 2);     // [NQ][NR]   q . Ek
-  float* pw_s = qe_s + NQ * NR;                    // [NQ][NR]   band probabilities (unnormalised)
+  uint4* evq = vq + VQ_UNITS;                      // Ev as one k step of V: [NP planes][96 channels][2 halves]
+  float* qe_s = reinterpret_cast<float*>(evq + NP * DK * 2);    // [NQ][NR]   q . Ek
+  float* pw_s = qe_s + NQ * NR;                    // [NQ][NR]   band scores (-inf: no such key)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int par = lane >> 5, l31 = lane & 31;
@@ -344,6 +369,7 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
   const float qscale = 1.f / sqrtf((float)DK);
   const int il = 32 * wave + l31;                  // this lane's query inside the block
   const int iq = i0 + il;
+  float amax = 0.f;                                // NP = 2: the largest operand magnitude this thread converted
 
   // ---- Q: staged (scaled, split) through the K / V tile space, then held in registers as B fragments ----
   for (int u = tid; u < NCG * NQ; u += NT) {
@@ -352,15 +378,18 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = qb[(long long)(8 * cg + e) * L + ii] * qscale;
-    att_split3_unit(v, att_m[(0 * NCG + cg) * NQ + i], att_m[(1 * NCG + cg) * NQ + i], att_m[(2 * NCG + cg) * NQ + i]);
+    uint4 pl[NP];
+    att_split_unit<NP>(v, pl, amax);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) att_m[(p * NCG + cg) * NQ + i] = pl[p];
   }
-  for (int idx = tid; idx < NQ * NR; idx += NT) pw_s[idx] = 0.f;
+  for (int idx = tid; idx < NQ * NR; idx += NT) pw_s[idx] = -INFINITY;
   __syncthreads();
-  uint4 Qf[6][3];                                  // [k step of 16 channels][plane]
+  uint4 Qf[6][NP];                                 // [k step of 16 channels][plane]
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) Qf[ks][p] = att_m[(p * NCG + 2 * ks + par) * NQ + il];
+    for (int p = 0; p < NP; ++p) Qf[ks][p] = att_m[(p * NCG + 2 * ks + par) * NQ + il];
   __syncthreads();
 
   // ---- Ek as a 32-"key" tile (rows >= 9 zero) for q . Ek; Ev as one k step of values ----
@@ -369,7 +398,10 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = r < NR ? ek[r * DK + 8 * cg + e] : 0.f;
-    att_split3_unit(v, kq[(0 * NCG + cg) * ATT_KT + r], kq[(1 * NCG + cg) * ATT_KT + r], kq[(2 * NCG + cg) * ATT_KT + r]);
+    uint4 pl[NP];
+    att_split_unit<NP>(v, pl, amax);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) kq[(p * NCG + cg) * ATT_KT + r] = pl[p];
   }
   for (int u = tid; u < DK * 2; u += NT) {
     const int c = u >> 1, hp = u & 1;              // k slot e of half hp <-> embedding row 8 * (e >> 2) + 4 * hp + (e & 3)
@@ -379,7 +411,10 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
       const int r = 8 * (e >> 2) + 4 * hp + (e & 3);
       v[e] = r < NR ? ev[r * DK + c] : 0.f;
     }
-    att_split3_unit(v, evq[(0 * DK + c) * 2 + hp], evq[(1 * DK + c) * 2 + hp], evq[(2 * DK + c) * 2 + hp]);
+    uint4 pl[NP];
+    att_split_unit<NP>(v, pl, amax);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) evq[(p * DK + c) * 2 + hp] = pl[p];
   }
   __syncthreads();
   {
@@ -388,10 +423,10 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
     for (int r = 0; r < 16; ++r) e[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
-      uint4 a[3];
+      uint4 a[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) a[p] = kq[(p * NCG + 2 * ks + par) * ATT_KT + l31];
-      e = att_mma6(a, Qf[ks], e);
+      for (int p = 0; p < NP; ++p) a[p] = kq[(p * NCG + 2 * ks + par) * ATT_KT + l31];
+      e = att_mma_split<NP>(a, Qf[ks], e);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -410,7 +445,10 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
       for (int e = 0; e < 8; ++e) v[e] = kp[(long long)e * L];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ok ? v[e] : 0.f;
-      att_split3_unit(v, kq[(0 * NCG + cg) * ATT_KT + j], kq[(1 * NCG + cg) * ATT_KT + j], kq[(2 * NCG + cg) * ATT_KT + j]);
+      uint4 pl[NP];
+      att_split_unit<NP>(v, pl, amax);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) kq[(p * NCG + cg) * ATT_KT + j] = pl[p];
     }
   };
   auto stage_v = [&](int jb) __attribute__((always_inline)) {
@@ -425,11 +463,14 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
         v[e] = vp[j < L ? j : L - 1];
         v[e] = j < L ? v[e] : 0.f;
       }
-      att_split3_unit(v, vq[(0 * DK + c) * 8 + s8], vq[(1 * DK + c) * 8 + s8], vq[(2 * DK + c) * 8 + s8]);
+      uint4 pl[NP];
+      att_split_unit<NP>(v, pl, amax);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) vq[(p * DK + c) * 8 + s8] = pl[p];
     }
   };
   // S' of the staged key tile for this wave's 32 queries, relative-position term and masking applied
-  auto scores = [&](int jb, att_f32x16 (&sc)[2]) __attribute__((always_inline)) {
+  auto scores = [&](int jb, bool near, att_f32x16 (&sc)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -438,14 +479,11 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
     for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        uint4 a[3];
+        uint4 a[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a[p] = kq[(p * NCG + 2 * ks + par) * ATT_KT + 32 * mt + l31];
-        sc[mt] = att_mma6(a, Qf[ks], sc[mt]);
+        for (int p = 0; p < NP; ++p) a[p] = kq[(p * NCG + 2 * ks + par) * ATT_KT + 32 * mt + l31];
+        sc[mt] = att_mma_split<NP>(a, Qf[ks], sc[mt]);
       }
-    // the band |j - i| <= W touches this tile only when the tile's keys come near the wave's queries
-    const int wq0 = i0 + 32 * wave;
-    const bool near = jb <= wq0 + 31 + W && jb + ATT_KT - 1 >= wq0 - W;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -461,49 +499,50 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
       }
   };
 
-  // ---- pass 1: row maxima ----
-  float mx = -INFINITY;
-  for (int jb = 0; jb < L; jb += ATT_KT) {
-    __syncthreads();
-    stage_k(jb);
-    __syncthreads();
-    att_f32x16 sc[2];
-    scores(jb, sc);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[mt][r]);
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-
-  // ---- pass 2: p = exp(s - max), row sums, p . v ----
+  // ---- one pass: scores, running maximum, p = exp(s - max), row sums, p . v ----
   att_f32x16 o[3];
 #pragma unroll
   for (int mc = 0; mc < 3; ++mc)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[mc][r] = 0.f;
-  float lsum = 0.f;
+  float lsum = 0.f, mx = -INFINITY;
   for (int jb = 0; jb < L; jb += ATT_KT) {
     __syncthreads();
     stage_k(jb);
     stage_v(jb);
     __syncthreads();
-    att_f32x16 sc[2];
-    scores(jb, sc);
+    // the band |j - i| <= W touches this tile only when the tile's keys come near the wave's queries
     const int wq0 = i0 + 32 * wave;
     const bool near = jb <= wq0 + 31 + W && jb + ATT_KT - 1 >= wq0 - W;
+    att_f32x16 sc[2];
+    scores(jb, near, sc);
+    float tm = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tm = fmaxf(tm, sc[mt][r]);
+    tm = fmaxf(tm, __shfl_xor(tm, 32));            // the other half of the tile's keys for the same query
+    // a tile always holds a key below L, whose score is finite: the new maximum is finite, and exp(-inf - it) = 0
+    const float mnew = fmaxf(mx, tm);
+    const float alpha = expf(mx - mnew);
+    mx = mnew;
+    lsum *= alpha;
+#pragma unroll
+    for (int mc = 0; mc < 3; ++mc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[mc][r] *= alpha;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = expf(sc[mt][r] - mx);      // exp(-inf) = 0 for keys beyond L
-        sc[mt][r] = p;
-        lsum += p;
         if (near) {
           const int j = jb + 32 * mt + 8 * (r >> 2) + 4 * par + (r & 3);
           const int d = j - iq + W;
-          if (d >= 0 && d < NR && j < L) pw_s[il * NR + d] = p;
+          if (d >= 0 && d < NR && j < L) pw_s[il * NR + d] = sc[mt][r];
         }
+        const float p = expf(sc[mt][r] - mx);      // exp(-inf) = 0 for keys beyond L
+        sc[mt][r] = p;
+        lsum += p;
       }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -512,36 +551,38 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
         float pv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) pv[e] = sc[mt][8 * hh + e];
-        uint4 pb[3];
-        att_split3_unit(pv, pb[0], pb[1], pb[2]);
+        uint4 pb[NP];
+        float unused = 0.f;                        // probabilities lie in [0, 1]
+        att_split_unit<NP>(pv, pb, unused);
         const int s8 = 2 * (2 * mt + hh) + par;
 #pragma unroll
         for (int mc = 0; mc < 3; ++mc) {
-          uint4 a[3];
+          uint4 a[NP];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) a[p] = vq[(p * DK + 32 * mc + l31) * 8 + s8];
-          o[mc] = att_mma6(a, pb, o[mc]);
+          for (int p = 0; p < NP; ++p) a[p] = vq[(p * DK + 32 * mc + l31) * 8 + s8];
+          o[mc] = att_mma_split<NP>(a, pb, o[mc]);
         }
       }
   }
   lsum += __shfl_xor(lsum, 32);
-  // ---- the band's probabilities times Ev: one more k step (LDS accesses of one wave complete in order, and pw_s rows
-  // are written and read by the two lanes of the same query only) ----
+  // ---- the band's probabilities (against the final maximum) times Ev: one more k step (LDS accesses of one wave
+  // complete in order, and pw_s rows are written and read by the two lanes of the same query only) ----
   {
     float pv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int r = 8 * (e >> 2) + 4 * par + (e & 3);
-      pv[e] = r < NR ? pw_s[il * NR + r] : 0.f;
+      pv[e] = r < NR ? expf(pw_s[il * NR + r] - mx) : 0.f;
     }
-    uint4 pb[3];
-    att_split3_unit(pv, pb[0], pb[1], pb[2]);
+    uint4 pb[NP];
+    float unused = 0.f;
+    att_split_unit<NP>(pv, pb, unused);
 #pragma unroll
     for (int mc = 0; mc < 3; ++mc) {
-      uint4 a[3];
+      uint4 a[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) a[p] = evq[(p * DK + 32 * mc + l31) * 2 + par];
-      o[mc] = att_mma6(a, pb, o[mc]);
+      for (int p = 0; p < NP; ++p) a[p] = evq[(p * DK + 32 * mc + l31) * 2 + par];
+      o[mc] = att_mma_split<NP>(a, pb, o[mc]);
     }
   }
   if (iq < L) {
@@ -552,18 +593,21 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) ob[(long long)(32 * mc + 4 * par + (r & 3) + 8 * (r >> 2)) * L] = o[mc][r] * rinv;
   }
+  if constexpr (NP == 2) {
+    if (range_flag && !(amax <= 65504.f)) atomicOr(range_flag, 1);
+  }
 }
 
-template <int NW>
+template <int NW, int NP>
 static hipError_t attention_mfma_launch(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
-                                  int B, int H, int L, hipStream_t s) {
+                                  int B, int H, int L, int* range_flag, hipStream_t s) {
   constexpr int NQ = 32 * NW;
-  const size_t lds = (size_t)(3 * ATT_NCG * ATT_KT + 3 * ATT_DK * 8 + 3 * ATT_DK * 2) * sizeof(uint4) +
+  const size_t lds = (size_t)(NP * ATT_NCG * ATT_KT + NP * ATT_DK * 8 + NP * ATT_DK * 2) * sizeof(uint4) +
                      (size_t)2 * NQ * (2 * ATT_W + 1) * sizeof(float);
   static LdsAttr attr;
-  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attention_mfma_kernel<NW>), lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((attention_mfma_kernel<NW>), dim3((L + NQ - 1) / NQ, H, B), dim3(64 * NW), lds, s, qkv, emb_k, emb_v,
-                     lengths, out, H, L);
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attention_mfma_kernel<NW, NP>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((attention_mfma_kernel<NW, NP>), dim3((L + NQ - 1) / NQ, H, B), dim3(64 * NW), lds, s, qkv, emb_k, emb_v,
+                     lengths, out, H, L, range_flag);
   return hipGetLastError();
 }
 
@@ -577,7 +621,7 @@ static int att_mfma_min_len() {
 }
 
 hipError_t launch_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
-                            int B, int H, int DK, int L, int window, hipStream_t s) {
+                            int B, int H, int DK, int L, int window, hipStream_t s, bool f16x2, int* range_flag) {
   if (DK != ATT_DK || window != ATT_W || B <= 0 || L <= 0 || L > 16384 || B > 65535) return hipErrorInvalidValue;
   // The matrix-core kernel is a block-serial walk over the keys (two passes, a barrier pair per 64 keys): it wins where
   // its grid fills the chip or the row is long (the other kernel's cost per query grows with L twice: scores and p.v on
@@ -585,9 +629,12 @@ hipError_t launch_attention(const float* qkv, const float* emb_k, const float* e
   const long long blocks64 = (long long)((L + 63) / 64) * H * B;
   if (att_mfma_min_len() > 0 && L >= att_mfma_min_len() && (L >= 2 * att_mfma_min_len() || blocks64 >= device_cu_count())) {
     // 128 queries a block when that still gives every CU two blocks, else 64
-    if ((long long)((L + 127) / 128) * H * B >= 2LL * device_cu_count())
-      return attention_mfma_launch<4>(qkv, emb_k, emb_v, lengths, out, B, H, L, s);
-    return attention_mfma_launch<2>(qkv, emb_k, emb_v, lengths, out, B, H, L, s);
+    const bool wide = (long long)((L + 127) / 128) * H * B >= 2LL * device_cu_count();
+    if (f16x2)
+      return wide ? attention_mfma_launch<4, 2>(qkv, emb_k, emb_v, lengths, out, B, H, L, range_flag, s)
+                  : attention_mfma_launch<2, 2>(qkv, emb_k, emb_v, lengths, out, B, H, L, range_flag, s);
+    return wide ? attention_mfma_launch<4, 3>(qkv, emb_k, emb_v, lengths, out, B, H, L, nullptr, s)
+                : attention_mfma_launch<2, 3>(qkv, emb_k, emb_v, lengths, out, B, H, L, nullptr, s);
   }
   if (L > 2048) return hipErrorInvalidValue;       // the lanes-on-keys kernel holds a whole score row in registers
   const int nch = (L + 63) / 64;

@@ -263,9 +263,11 @@ int run_encoder(const vits_model* m, int which, float* x, const int* lengths, in
   const float *pg = nullptr, *pb = nullptr, *ps = nullptr;      // the pending LayerNorm of x: gain, bias, statistics
   for (size_t i = 0; i < layers.size(); ++i) {
     const EncLayer& l = layers[i];
+    // an encoder whose convs have the f16x2 packing (frame rate) runs its attention in the same arithmetic
+    const bool att_f16x2 = l.qkv.w_alt && l.o.w_alt && alt_f16x2_mode() > 0;
     if (!deferred) {
       TRY(conv_simple(l.qkv, x, qkv, B, L, lengths, 0, s));
-      HIP_TRY(launch_attention(qkv, l.ek, l.ev, lengths, att, B, H, C / H, L, m->cfg.window_size, s));
+      HIP_TRY(launch_attention(qkv, l.ek, l.ev, lengths, att, B, H, C / H, L, m->cfg.window_size, s, att_f16x2, g_range_flag));
       TRY(conv_simple(l.o, att, x, B, L, lengths, F_RES, s, x));
       HIP_TRY(launch_layer_norm(x, x, l.ln1g, l.ln1b, lengths, B, C, L, false, s));
       TRY(conv_simple(l.ffn1, x, h, B, L, lengths, F_IN_MASK | F_RELU, s));
@@ -279,7 +281,7 @@ int run_encoder(const vits_model* m, int which, float* x, const int* lengths, in
       a.ln_in_stats = ps; a.ln_in_gamma = pg; a.ln_in_beta = pb;
       HIP_TRY(launch_conv(l.qkv, a, s));
     }
-    HIP_TRY(launch_attention(qkv, l.ek, l.ev, lengths, att, B, H, C / H, L, m->cfg.window_size, s));
+    HIP_TRY(launch_attention(qkv, l.ek, l.ev, lengths, att, B, H, C / H, L, m->cfg.window_size, s, att_f16x2, g_range_flag));
     {
       ConvArgs a = conv_simple_args(l.o, att, x, B, L, lengths, F_RES, x);
       a.ln_res_stats = ps; a.ln_res_gamma = pg; a.ln_res_beta = pb;
@@ -1374,6 +1376,15 @@ int vits_op_layer_norm(const float* x, float* y, const float* gamma, const float
 int vits_op_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out, int B,
                       int H, int DK, int L, int window, void* stream) {
   HIP_TRY(launch_attention(qkv, emb_k, emb_v, lengths, out, B, H, DK, L, window, (hipStream_t)stream));
+  return VITS_OK;
+}
+
+int vits_op_attention_prec(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out, int B,
+                           int H, int DK, int L, int window, int precision, void* stream) {
+  if (precision != PREC_BF16X3 && precision != PREC_F16X2)
+    return fail(VITS_ERR_INVALID, "attention: precision must be bf16x3 (1) or f16x2 (3)");
+  HIP_TRY(launch_attention(qkv, emb_k, emb_v, lengths, out, B, H, DK, L, window, (hipStream_t)stream,
+                           precision == PREC_F16X2, g_range_flag));
   return VITS_OK;
 }
 
