@@ -5,7 +5,7 @@ generator kernels, both or none were resident.  usage  python tools/overlap_anal
 import csv
 import sys
 
-GEN = ("conv_gl", "resblock_pair", "conv_f16x2", "stage_f16x2", "conv_to1_vec4")
+GEN = ("@gen",)
 
 
 def union(iv):
@@ -42,6 +42,10 @@ def main():
     skip = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 0.0
     ks = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")) for r in rows]
     ks.sort(key=lambda k: k[1])
+    # generator kernels: everything on a queue that carried a ResBlock kernel (the generator's stream and its side
+    # streams; the front end has a queue of its own in throughput mode, and shares some kernel templates)
+    gen_q = {k[3] for k in ks if "resblock_" in k[0] or "conv_gl16" in k[0]}
+    ks = [(k[0] + (" @gen" if k[3] in gen_q else ""), k[1], k[2], k[3]) for k in ks]
     # the traced region: from the first generator kernel after `skip` to the last generator kernel
     gens = [k for k in ks if any(g in k[0] for g in GEN)]
     t_begin = gens[0][1] + skip

@@ -171,6 +171,7 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
 // true when launch_conv would run this conv on the split-K kernel for a batch of B rows of L steps (the only kernel
 // that honours ConvArgs::ln_*)
 bool conv_takes_split_k(const ConvDesc& d, int B, int L);
+bool alt_prefers_f16x2(int B, int L);   // a conv with the f16x2 packing skips the split-K kernel at this size
 void set_alt_f16x2_mode(int mode);      // ConvDesc::w_alt: 0 never, 1 launches beyond the split-K kernel (default), 2 always
 int alt_f16x2_mode();
 

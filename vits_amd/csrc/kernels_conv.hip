@@ -2581,7 +2581,7 @@ static int ks_choice(bool gate, int M, int Cin, int K, int L, int B, int halo, b
 
 bool conv_takes_split_k(const ConvDesc& d, int B, int L) {
   bool eight;
-  if (d.w_alt && alt_f16x2_mode() >= 2) return false;
+  if (d.w_alt && alt_prefers_f16x2(B, L)) return false;
   return d.prec == PREC_BF16X3 && (d.mode == MODE_PLAIN || d.mode == MODE_GATE) &&
          ks_choice(d.mode == MODE_GATE, d.M, d.Cin, d.K, L, B, d.max_off - d.min_off, &eight) > 0;
 }
@@ -2629,6 +2629,19 @@ static std::atomic<int> g_alt_mode{[] {
 }()};
 void set_alt_f16x2_mode(int mode) { g_alt_mode.store(mode < 0 ? 0 : mode > 2 ? 2 : mode); }
 int alt_f16x2_mode() { return g_alt_mode.load(); }
+// A conv that has the f16x2 packing leaves the split-K kernel to it: always in mode 2; in mode 1 from
+// VITS_FE_F16X2_COLS (default 2048) time steps over the whole batch on.  The split-K kernel is built for latency (four
+// waves share one output tile's reduction); from a few thousand columns on the one-role kernel does the same conv in
+// half the products and a fraction of the block-time, which is what the generator running beside the front end in
+// throughput mode gets back (C2: +1 %); at batch 1 the split-K kernel stays.
+bool alt_prefers_f16x2(int B, int L) {
+  static const long long min_cols = [] {
+    const char* e = getenv("VITS_FE_F16X2_COLS");
+    return e && e[0] ? atoll(e) : 2048LL;
+  }();
+  const int mode = alt_f16x2_mode();
+  return mode >= 2 || (mode == 1 && (long long)B * L >= min_cols);
+}
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   if (d.Cin % 16 != 0 || d.M % 32 != 0 || d.K < 1 || d.K > MAX_TAPS) return hipErrorInvalidValue;
@@ -2675,7 +2688,7 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
     // second destination, deferred LayerNorm)
     const bool alt_ok = d.w_alt && !a.split_row && !a.ln_in_stats && !a.ln_res_stats && !a.ln_out_stats && M % 64 == 0;
     const int alt = alt_ok ? alt_f16x2_mode() : 0;
-    if (alt < 2) {
+    if (!(alt_ok && alt_prefers_f16x2(a.B, a.L))) {
       hipError_t err = hipSuccess;
       ConvArgs ak = a;
       if (d.mode == MODE_PLAIN ? try_launch_ks<MODE_PLAIN>(ak, stream, err) : try_launch_ks<MODE_GATE>(ak, stream, err))
