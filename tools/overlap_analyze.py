@@ -37,11 +37,38 @@ def intersect(a, b):
     return out
 
 
+def front_end_block_time(rows):
+    """What the front end takes from the generator beside it: a block of a front-end kernel holds one of the chip's
+    block slots (two per CU for the generator's large kernels) for as long as its kernel runs -- an upper bound, in
+    microseconds of the whole chip per launch = duration x min(blocks, 512) / 512, summed per kernel class."""
+    gen_q = {r["Queue_Id"] for r in rows if "resblock_" in r["Kernel_Name"] or "conv_gl16" in r["Kernel_Name"]}
+    agg = {}
+    for r in rows:
+        if r["Queue_Id"] in gen_q:
+            continue
+        name = r["Kernel_Name"].replace("void vits::", "").replace("(anonymous namespace)::", "").split("(")[0][:56]
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        blocks = 1
+        for ax in "XYZ":
+            blocks *= max(1, int(r["Grid_Size_" + ax]) // max(1, int(r["Workgroup_Size_" + ax])))
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0])
+        a[0] += 1
+        a[1] += d
+        a[2] += d * min(blocks, 512) / 512
+        a[3] += blocks
+    total = sum(a[2] for a in agg.values())
+    print(f"front-end kernels (every queue without a ResBlock kernel): {sum(a[0] for a in agg.values())} launches, "
+          f"{total / 1e3:.2f} ms of chip-equivalent block time")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:12]:
+        print(f"  {k:56s} {a[0]:5d} launches  avg {a[1] / a[0]:7.1f} us  avg {a[3] / a[0]:7.1f} blocks  {a[2] / 1e3:7.2f} ms chip-equivalent")
+
+
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     skip = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 0.0
     ks = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")) for r in rows]
     ks.sort(key=lambda k: k[1])
+    front_end_block_time(rows)
     # generator kernels: everything on a queue that carried a ResBlock kernel (the generator's stream and its side
     # streams; the front end has a queue of its own in throughput mode, and shares some kernel templates)
     gen_q = {k[3] for k in ks if "resblock_" in k[0] or "conv_gl16" in k[0]}

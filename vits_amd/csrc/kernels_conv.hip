@@ -1158,7 +1158,8 @@ __global__ __launch_bounds__(256, WM * WN > 4 ? 2 : 3) void conv_bf16_kernel(con
 // (~1800 cycles a tap measured at batch 1, against 384 cycles of MFMAs).  The variant keeps the fragments of the next
 // RING taps in flight in a register ring (slots are compile-time: the tap loop is flat and unrolled RING times) and
 // spends the registers that occupancy does not need.  Same operands in the same order: bit-identical results.
-template <int WM, int WN, int WGM, int WGN, int MODE, bool STG = false, int RING = 0>
+// EX: optional epilogue features beyond the staged copy (EPI_SPLIT: WaveNet's res / skip conv with two destinations)
+template <int WM, int WN, int WGM, int WGN, int MODE, bool STG = false, int RING = 0, int EX = 0>
 __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x2_kernel(const ConvArgs a) {
   constexpr int BN = 32 * WN * WGN;
   constexpr int NCT = (BN + MAX_HALO + 255) / 256;       // tile columns per thread
@@ -1413,7 +1414,7 @@ __global__ __launch_bounds__(256, RING ? 2 : WM * WN > 4 ? 2 : 3) void conv_f16x
       return;
     }
   }
-  conv_epilogue<WM, WN, MODE, true, (STG || MODE == MODE_UP8 || MODE == MODE_UP4) ? EPI_OUT2 : 0>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
+  conv_epilogue<WM, WN, MODE, true, (STG || MODE == MODE_UP8 || MODE == MODE_UP4) ? EPI_OUT2 : EX>(a, acc, mt, mt_ok, wn, par, l31, t0, b, len_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2176,6 +2177,23 @@ static hipError_t launch_h2(ConvArgs& a, hipStream_t stream) {
   dim3 grid((a.L + BN - 1) / BN, (units + WGM - 1) / WGM, a.B);
   const size_t lds = (size_t)4 * a.rs * sizeof(uint4);
   char name[96];
+  if (a.split_row) {
+    // two destinations: one tile shape is built with that epilogue (the 128-row block of launch_conv's direct route)
+    if constexpr (MODE == MODE_PLAIN && WM == 2 && WN == 2 && WGM == 2 && WGN == 2) {
+      if (a.flags & F_IN_STAGED) return hipErrorInvalidValue;
+      const bool ring = (long long)grid.x * grid.y * grid.z <= (long long)f16x2_ring_blocks_per_cu() * device_cu_count();
+      snprintf(name, sizeof name, "conv_f16x2_kernel<%d,%d,%d,%d,%d,split%s>", WM, WN, WGM, WGN, MODE, ring ? ",ring" : "");
+      return timed_launch(name, false, a, stream, [&] {
+        if (ring)
+          hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, WGM, WGN, MODE, false, F16X2_RING, EPI_SPLIT>), grid, dim3(256), lds,
+                             stream, a);
+        else
+          hipLaunchKernelGGL((conv_f16x2_kernel<WM, WN, WGM, WGN, MODE, false, 0, EPI_SPLIT>), grid, dim3(256), lds, stream, a);
+      });
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if constexpr (MODE == MODE_PLAIN && WM == 2 && (WN == 2 || (WN == 1 && WGM == 2))) {
     // a grid of at most two blocks per CU is a set of serial chains: the weight-ring variant
     if ((long long)grid.x * grid.y * grid.z <= (long long)f16x2_ring_blocks_per_cu() * device_cu_count()) {
@@ -2686,7 +2704,13 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   if (p == PREC_BF16X3 && (d.mode == MODE_PLAIN || d.mode == MODE_GATE)) {
     // the f16x2 packing, where the conv has one and uses nothing the f16x2 kernel's epilogue is not built with (a
     // second destination, deferred LayerNorm)
-    const bool alt_ok = d.w_alt && !a.split_row && !a.ln_in_stats && !a.ln_res_stats && !a.ln_out_stats && M % 64 == 0;
+    // (a second destination: the 128-row tile shape only)
+    static const bool split_too = [] {            // VITS_FE_SPLIT_F16X2=0: two-destination convs stay bf16x3 (A/B)
+      const char* e = getenv("VITS_FE_SPLIT_F16X2");
+      return !(e && e[0] == '0');
+    }();
+    const bool alt_ok = d.w_alt && !a.ln_in_stats && !a.ln_res_stats && !a.ln_out_stats && M % 64 == 0 &&
+                        (!a.split_row || (split_too && M % 128 == 0 && d.mode == MODE_PLAIN));
     const int alt = alt_ok ? alt_f16x2_mode() : 0;
     if (!(alt_ok && alt_prefers_f16x2(a.B, a.L))) {
       hipError_t err = hipSuccess;
@@ -2701,6 +2725,7 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
   }
   switch (d.mode) {
     case MODE_PLAIN:
+      if (a.split_row && p == PREC_F16X2) return launch_cfg<2, 2, 2, 2, MODE_PLAIN>(a, p, stream);
       if (M % 64 == 0) {
         if (L <= 96 && M % 128 == 0) return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, p, stream);
         // a grid that leaves most CUs empty (batch 1): 128 x 64 tiles, twice the blocks, half the chain

@@ -623,11 +623,13 @@ static int att_mfma_min_len() {
 hipError_t launch_attention(const float* qkv, const float* emb_k, const float* emb_v, const int* lengths, float* out,
                             int B, int H, int DK, int L, int window, hipStream_t s, bool f16x2, int* range_flag) {
   if (DK != ATT_DK || window != ATT_W || B <= 0 || L <= 0 || L > 16384 || B > 65535) return hipErrorInvalidValue;
-  // The matrix-core kernel is a block-serial walk over the keys (two passes, a barrier pair per 64 keys): it wins where
-  // its grid fills the chip or the row is long (the other kernel's cost per query grows with L twice: scores and p.v on
-  // the vector ALUs); a short row in a small batch (batch-1 latency at 258 frames: 10 blocks) stays with the other one.
+  // The matrix-core kernel is a block-serial walk over the keys (a barrier pair per 64 keys): it wins where its grid
+  // gives at least every second CU a block or the row is long (the other kernel's cost per query grows with L twice:
+  // scores and p.v on the vector ALUs); a short row in a small batch (batch-1 latency at 258 frames: 10 blocks) stays
+  // with the other one.  (16 x 258 frames, 160 blocks: 60 against 67 us alone, and beside the generator in throughput
+  // mode its 160 two-wave blocks take less of the chip than the other kernel's 544: +0.5 % on the whole job.)
   const long long blocks64 = (long long)((L + 63) / 64) * H * B;
-  if (att_mfma_min_len() > 0 && L >= att_mfma_min_len() && (L >= 2 * att_mfma_min_len() || blocks64 >= device_cu_count())) {
+  if (att_mfma_min_len() > 0 && L >= att_mfma_min_len() && (L >= 2 * att_mfma_min_len() || 2 * blocks64 >= device_cu_count())) {
     // 128 queries a block when that still gives every CU two blocks, else 64
     const bool wide = (long long)((L + 127) / 128) * H * B >= 2LL * device_cu_count();
     if (f16x2)
