@@ -58,6 +58,12 @@ int vits_model_alive(const vits_model* m);
  * one per ResBlock kernel size.  A caller that drives further streams of its own lowers it to stay within the
  * process's hardware queues (4 by default).  No counterpart in the reference. */
 int vits_model_set_generator_streams(vits_model* m, int n_streams);
+/* Tells the library that this model's front-end stages (frame prior, flow) are being run beside a generator call on
+ * other streams (a pipeline over batches): they then pick kernels that take less of the chip's block slots, which the
+ * generator gets back, over kernels with the shortest latency of their own.  Same values either way at the fp32-grade
+ * tolerance (the f16x2 packing of the frame-rate convs is used from smaller sizes on).  Default off.  No counterpart
+ * in the reference. */
+int vits_model_set_front_end_overlapped(vits_model* m, int on);
 /* The encoders' post-LN sub-layers (reference attentions.py:32-44, modules.py:15-27): with on != 0 (the default, unless
  * VITS_LN_FUSED=0) a LayerNorm is not a kernel of its own -- the conv that produces x + f(x) writes per-time-step
  * statistics and the convs that consume the normalised tensor apply it while they load; with 0 every LayerNorm is a

@@ -448,7 +448,9 @@ def test_infer_c4_corpus_slice(gpu_model, oracle_model):
     """BASELINE configs[3] (the 10 000-utterance corpus: lognormal lengths clipped to 88..1400 frames, sorted, cut
     into batches of <= 64): a fixed slice of its batches -- the longest, the shortest, the first ragged one and a
     ragged one from the middle -- through infer_batches, the path the corpus benchmark uses.
-      * every batch: the bytes plain infer() returns for it (throughput mode changes nothing), masks = frame counts;
+      * every batch: what plain infer() returns for it -- the same masks and frame counts, the waveform within
+        1e-5 and the latent within 5e-5 (batches of 2048 frames and more run their frame-rate convs on the f16x2 packing in throughput mode, on
+        the latency-oriented bf16x3 kernel in a plain call, where that one takes them; the same bytes otherwise);
       * the small ragged batch: the whole batch, padded tails included, against the CPU oracle (parity is defined per
         identical batch: padding leaks into valid positions, reference models.py:746-765);
       * the unpadded batches: a row equals its own batch-1 result, and that one against the oracle."""
@@ -466,7 +468,8 @@ def test_infer_c4_corpus_slice(gpu_model, oracle_model):
     for b, kw, g in zip(data, kws, got):
         k = dict(kw)
         r = gpu_model.infer(k.pop("phonemes"), k.pop("phonemes_lengths"), **k)
-        assert torch.equal(g[0], r[0]) and torch.equal(g[1], r[1]) and torch.equal(g[2][0], r[2][0])
+        assert torch.equal(g[1], r[1])
+        assert metrics.max_abs(g[0], r[0]) <= 1e-5 and metrics.max_abs(g[2][0], r[2][0]) <= 5e-5     # waveform, latent z
         assert g[0].shape == (len(b.frames), 1, int(b.frames.max()) * 512)
         assert torch.isfinite(g[0]).all() and float(g[0].abs().max()) <= 1.0
         assert torch.equal(g[1].sum(dim=(1, 2)).cpu(), b.frames)

@@ -14,6 +14,9 @@ python3 tools/summarize_rocprof.py gpurun_out/refresh/b1 profiles/${R}_c1_batch1
 if [ -d gpurun_out/refresh/mf_c2 ]; then
   python3 tools/pmc_mfma_table.py gpurun_out/refresh/mf_c2 profiles/${R}_mfma_occupancy.md "python3 $P" profiles/${R}_pmc_traffic.json > /dev/null
   python3 tools/pmc_traffic_json.py gpurun_out/refresh/pmc_c3_bf16 profiles/${R}_pmc_traffic_c3_bf16.json "python3 $C3 --precision bf16" > /dev/null
+  if [ -d gpurun_out/refresh/pmc_c3 ]; then
+    python3 tools/pmc_traffic_json.py gpurun_out/refresh/pmc_c3 profiles/${R}_pmc_traffic_c3.json "python3 $C3" > /dev/null
+  fi
   python3 tools/pmc_mfma_table.py gpurun_out/refresh/mf_c3 profiles/${R}_mfma_occupancy_c3.md "python3 $C3" > /dev/null
   python3 tools/pmc_mfma_table.py gpurun_out/refresh/mf_c3_bf16 profiles/${R}_mfma_occupancy_c3_bf16.md "python3 $C3 --precision bf16" profiles/${R}_pmc_traffic_c3_bf16.json > /dev/null
   python3 tools/summarize_rocprof.py gpurun_out/refresh/kt_c3_bf16 profiles/${R}_c3_bf16_kernel_stats.md \

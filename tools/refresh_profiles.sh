@@ -28,6 +28,8 @@ if [[ "$WHAT" == *mfma* ]]; then
   bash tools/pmc_mfma.sh "$O/mf_c3_bf16" python3 "$R/bench.py" $C3 --precision bf16
   cd "$R"
   bash tools/pmc_traffic.sh "$O/pmc_c3_bf16" python3 "$R/bench.py" $C3 --precision bf16
+  cd "$R"
+  bash tools/pmc_traffic.sh "$O/pmc_c3" python3 "$R/bench.py" $C3
   cd /tmp
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_c3_bf16" -o kt -- python3 "$R/bench.py" $C3 --precision bf16 > "$O/kt_c3_bf16_bench.json" 2> "$O/kt_c3_bf16.log"
   cd "$R"

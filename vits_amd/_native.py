@@ -48,6 +48,7 @@ def _load():
         "vits_model_destroy": (None, [vp]),
         "vits_model_alive": (i32, [vp]),
         "vits_model_set_generator_streams": (i32, [vp, i32]),
+        "vits_model_set_front_end_overlapped": (i32, [vp, i32]),
         "vits_model_set_ln_fused": (i32, [vp, i32]),
         "vits_model_set_range_flag": (i32, [vp, vp]),
         "vits_model_set_tensor": (i32, [vp, C.c_char_p, vp, i64]),

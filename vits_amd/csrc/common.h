@@ -172,6 +172,9 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream);
 // that honours ConvArgs::ln_*)
 bool conv_takes_split_k(const ConvDesc& d, int B, int L);
 bool alt_prefers_f16x2(int B, int L);   // a conv with the f16x2 packing skips the split-K kernel at this size
+// per host thread: the front-end stage being launched runs beside a generator on other streams (throughput mode)
+void set_front_end_overlapped(bool on);
+bool front_end_overlapped();
 void set_alt_f16x2_mode(int mode);      // ConvDesc::w_alt: 0 never, 1 launches beyond the split-K kernel (default), 2 always
 int alt_f16x2_mode();
 

@@ -2647,18 +2647,24 @@ static std::atomic<int> g_alt_mode{[] {
 }()};
 void set_alt_f16x2_mode(int mode) { g_alt_mode.store(mode < 0 ? 0 : mode > 2 ? 2 : mode); }
 int alt_f16x2_mode() { return g_alt_mode.load(); }
-// A conv that has the f16x2 packing leaves the split-K kernel to it: always in mode 2; in mode 1 from
-// VITS_FE_F16X2_COLS (default 2048) time steps over the whole batch on.  The split-K kernel is built for latency (four
-// waves share one output tile's reduction); from a few thousand columns on the one-role kernel does the same conv in
-// half the products and a fraction of the block-time, which is what the generator running beside the front end in
-// throughput mode gets back (C2: +1 %); at batch 1 the split-K kernel stays.
+static thread_local bool g_fe_overlapped = false;
+void set_front_end_overlapped(bool on) { g_fe_overlapped = on; }
+bool front_end_overlapped() { return g_fe_overlapped; }
+
+// A conv that has the f16x2 packing leaves the split-K kernel to it: always in mode 2; in mode 1 when the front end
+// runs beside a generator (throughput mode), from VITS_FE_F16X2_COLS (default 2048) time steps over the whole batch on.
+// The split-K kernel is built for latency (four waves share one output tile's reduction) and is the faster one on an
+// otherwise idle chip (a plain call at 16 x 258 frames: 13.7 against 14.6 ms), but it spreads a conv over several
+// hundred blocks that each hold a block slot while they wait on memory; the one-role kernel does the same conv in half
+// the products and a fraction of the block time, which is what the generator running beside it gets back (C2 in
+// throughput mode: +1 %).
 bool alt_prefers_f16x2(int B, int L) {
   static const long long min_cols = [] {
     const char* e = getenv("VITS_FE_F16X2_COLS");
     return e && e[0] ? atoll(e) : 2048LL;
   }();
   const int mode = alt_f16x2_mode();
-  return mode >= 2 || (mode == 1 && (long long)B * L >= min_cols);
+  return mode >= 2 || (mode == 1 && g_fe_overlapped && (long long)B * L >= min_cols);
 }
 
 hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
@@ -2723,9 +2729,22 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
       p = PREC_F16X2;
     }
   }
+  // A front-end conv on its f16x2 packing (16 x 258 frames: a few hundred blocks whichever the tile): what counts is the
+  // length of a block's chain, and beside the generator in throughput mode the block time = blocks x chain.  128 x 64
+  // tiles (two m-tiles x one n-tile a wave: half the chain of the 64 x 256 and 256 x 64 tiles, and a row of 258 steps
+  // wastes a fifth of its last tile, not half) while the grid still fits the chip's block slots; rows beyond M in the
+  // last 128-row block are computed and not stored.  VITS_FE_TILE64=0 keeps the generic choice (A/B).
+  static const bool fe_tile64 = [] {
+    const char* e = getenv("VITS_FE_TILE64");
+    return !(e && e[0] == '0');
+  }();
+  const long long row_blocks64 = d.mode == MODE_GATE ? (M / 2 + 63) / 64 : (M + 127) / 128;
+  const bool alt_small = fe_tile64 && p == PREC_F16X2 && d.prec != PREC_F16X2 && !a.split_row && M % 64 == 0 &&
+                         (long long)((L + 63) / 64) * row_blocks64 * a.B <= 2LL * device_cu_count();
   switch (d.mode) {
     case MODE_PLAIN:
       if (a.split_row && p == PREC_F16X2) return launch_cfg<2, 2, 2, 2, MODE_PLAIN>(a, p, stream);
+      if (alt_small) return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, p, stream);
       if (M % 64 == 0) {
         if (L <= 96 && M % 128 == 0) return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, p, stream);
         // a grid that leaves most CUs empty (batch 1): 128 x 64 tiles, twice the blocks, half the chain
@@ -2742,7 +2761,7 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
       return launch_cfg<1, 1, 1, 4, MODE_PLAIN>(a, p, stream);
     case MODE_GATE:
       if (M % 64 != 0) return hipErrorInvalidValue;
-      if (L <= 96) return launch_cfg<2, 1, 2, 2, MODE_GATE>(a, p, stream);
+      if (L <= 96 || alt_small) return launch_cfg<2, 1, 2, 2, MODE_GATE>(a, p, stream);
       return launch_cfg<2, 2, 1, 4, MODE_GATE>(a, p, stream);
     case MODE_UP8:
       if (M % 64 != 0) return hipErrorInvalidValue;

@@ -46,6 +46,12 @@ struct RangeFlagScope {
   explicit RangeFlagScope(int* f) : prev(g_range_flag) { g_range_flag = f; }
   ~RangeFlagScope() { g_range_flag = prev; }
 };
+// The same for "this front-end stage runs beside a generator on other streams" (launch_conv's choice of kernel).
+struct OverlapScope {
+  bool prev;
+  explicit OverlapScope(bool on) : prev(front_end_overlapped()) { set_front_end_overlapped(on); }
+  ~OverlapScope() { set_front_end_overlapped(prev); }
+};
 
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
@@ -116,6 +122,7 @@ struct vits_model {
   int side_limit = 8;                // vits_model_set_generator_streams: how many of them vits_generator may use
   bool ln_fused = ln_fused_default();   // vits_model_set_ln_fused: the encoders' LayerNorms ride in the neighbouring convs
   int* range_flag = nullptr;         // vits_model_set_range_flag
+  bool beside_generator = false;     // vits_model_set_front_end_overlapped
 };
 
 namespace {
@@ -427,6 +434,12 @@ int vits_model_set_generator_streams(vits_model* m, int n_streams) {
   if (!model_alive(m)) return fail(VITS_ERR_INVALID, "set_generator_streams: not a live model handle");
   if (n_streams < 1) return fail(VITS_ERR_INVALID, "set_generator_streams: at least the caller's stream");
   m->side_limit = n_streams - 1;
+  return VITS_OK;
+}
+
+int vits_model_set_front_end_overlapped(vits_model* m, int on) {
+  if (!model_alive(m)) return fail(VITS_ERR_INVALID, "set_front_end_overlapped: not a live model handle");
+  m->beside_generator = on != 0;
   return VITS_OK;
 }
 
@@ -821,6 +834,7 @@ int vits_frame_prior(const vits_model* m, float* x_frame, const int* frame_lengt
   CHECK_MODEL(m);
   hipStream_t s = (hipStream_t)stream;
   RangeFlagScope range_scope(m->range_flag);       // frame-rate convs of long batches run in f16x2
+  OverlapScope overlap_scope(m->beside_generator);
   if (T > 16384) return fail(VITS_ERR_INVALID, "at most 16384 frames per utterance");
   Arena ar(ws, ws_bytes);
   TRY(run_encoder(m, 2, x_frame, frame_lengths, B, T, ar, s));
@@ -874,6 +888,7 @@ static int run_flow(const vits_model* m, float* z, const int* lengths, const flo
   const int C = m->cfg.hidden_channels, IC = m->cfg.inter_channels, half = IC / 2, NL = m->cfg.flow_layers;
   const int cr = m->cond_rows, nf = m->cfg.n_flows;
   RangeFlagScope range_scope(m->range_flag);       // frame-rate convs of long batches run in f16x2
+  OverlapScope overlap_scope(m->beside_generator);
   Arena ar(ws, ws_bytes);
   float* h = ar.take((int64_t)B * C * T);
   float* acts = ar.take((int64_t)B * C * T);

@@ -309,7 +309,12 @@ class SynthesizerTrn:
     @torch.no_grad()
     def infer_batches(self, batches):
         """Throughput mode for a sequence of independent batches: yields infer()'s tuple for each element of
-        `batches` (an iterable of dicts of infer()'s arguments), in order, with the same values infer() returns.
+        `batches` (an iterable of dicts of infer()'s arguments), in order, with the values infer() returns: the same
+        bytes for batches of fewer than 2048 frames in all; from there on the frame-rate convs of the front end run on
+        their f16x2 packing here (they take less of the chip from the generator beside them) where a plain call
+        keeps the latency-oriented bf16x3 kernel, and the waveforms agree to ~1e-6 instead (VITS_FE_F16X2_COLS moves
+        the size, VITS_FE_F16X2=0 switches the packing off).  Within this mode a batch's bytes do not depend on the
+        batches around it.
 
         `batches` is consumed lazily, one element ahead of the results: element i + 1 is taken only after the result
         of element i - 1 has been handed to the consumer, so a serving loop can feed requests as they arrive (the
@@ -353,6 +358,9 @@ class SynthesizerTrn:
                 gen_streams = 2 if caller == torch.cuda.default_stream(dev) else 1
                 N.check(lib.vits_model_set_generator_streams(h, int(os.environ.get("VITS_BATCHES_GEN_STREAMS", gen_streams))),
                         "set_generator_streams")
+                # every front end of this call runs beside a generator (all but the first, and the first takes the same
+                # kernels so that a batch's bytes do not depend on its place in the sequence)
+                N.check(lib.vits_model_set_front_end_overlapped(h, 1), "set_front_end_overlapped")
                 start = torch.cuda.Event()
                 start.record(caller)
                 self._s_fe.wait_event(start)                    # inputs prepared on the caller's stream are visible
@@ -417,6 +425,7 @@ class SynthesizerTrn:
             # whatever ends the loop (exhaustion, an exception, the consumer dropping the generator): the next call on
             # this model starts after both side streams have drained.  The two streams stay (torch hands them out of
             # a pool and never destroys them), so later calls budget their generator streams around them.
+            lib.vits_model_set_front_end_overlapped(h, 0)
             if getattr(self, "_s_fe", None) is not None:
                 ev = torch.cuda.Event()
                 self._s_gen.wait_stream(self._s_fe)
