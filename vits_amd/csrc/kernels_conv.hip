@@ -2087,12 +2087,14 @@ static hipError_t launch_b1(ConvArgs& a, hipStream_t stream) {
 constexpr int F16X2_RING = 6;
 // The ring variant takes grids of at most VITS_CONV_RING blocks per CU (default 2, what its register count lets be
 // resident; 0 keeps every launch on the occupancy-oriented kernel, for A/B measurements).
+// A front-end launch beside a generator (throughput mode) stays on the occupancy-oriented kernel whatever its grid: the
+// ring variant's blocks need a slot as large as the generator's own blocks and wait for one (C2: +0.45 % without it).
 static int f16x2_ring_blocks_per_cu() {
   static const int n = [] {
     const char* e = getenv("VITS_CONV_RING");
     return e && e[0] ? atoi(e) : 2;
   }();
-  return n;
+  return front_end_overlapped() ? 0 : n;
 }
 
 // VITS_CONV_GL=0 keeps staged-input convs on the register-staged kernel (A/B measurements).
@@ -2729,17 +2731,18 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
       p = PREC_F16X2;
     }
   }
-  // A front-end conv on its f16x2 packing (16 x 258 frames: a few hundred blocks whichever the tile): what counts is the
-  // length of a block's chain, and beside the generator in throughput mode the block time = blocks x chain.  128 x 64
-  // tiles (two m-tiles x one n-tile a wave: half the chain of the 64 x 256 and 256 x 64 tiles, and a row of 258 steps
-  // wastes a fifth of its last tile, not half) while the grid still fits the chip's block slots; rows beyond M in the
-  // last 128-row block are computed and not stored.  VITS_FE_TILE64=0 keeps the generic choice (A/B).
+  // A front-end conv on its f16x2 packing whose grid is a few hundred blocks whichever the tile (32 x 258 frames), on
+  // an otherwise idle chip: what counts is the length of a block's chain.  128 x 64 tiles (two m-tiles x one n-tile a
+  // wave: half the chain of the 64 x 256 and 256 x 64 tiles, and a row of 258 steps wastes a fifth of its last tile,
+  // not half) while the grid still fits the chip's block slots; rows beyond M in the last 128-row block are computed
+  // and not stored.  Plain calls at 16 x 258 with the packing forced: 15.08 -> 14.61 ms.  Beside a generator the generic
+  // choice stays (fewer, larger blocks: +0.2 %).  VITS_FE_TILE64=0 keeps the generic choice everywhere (A/B).
   static const bool fe_tile64 = [] {
     const char* e = getenv("VITS_FE_TILE64");
     return !(e && e[0] == '0');
   }();
   const long long row_blocks64 = d.mode == MODE_GATE ? (M / 2 + 63) / 64 : (M + 127) / 128;
-  const bool alt_small = fe_tile64 && p == PREC_F16X2 && d.prec != PREC_F16X2 && !a.split_row && M % 64 == 0 &&
+  const bool alt_small = fe_tile64 && !front_end_overlapped() && p == PREC_F16X2 && d.prec != PREC_F16X2 && !a.split_row && M % 64 == 0 &&
                          (long long)((L + 63) / 64) * row_blocks64 * a.B <= 2LL * device_cu_count();
   switch (d.mode) {
     case MODE_PLAIN:
