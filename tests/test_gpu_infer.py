@@ -444,6 +444,29 @@ def test_frame_rate_convs_in_f16x2_match_the_goldens(gpu_model):
         N.lib.vits_set_front_end_f16x2(1)
 
 
+def test_front_end_beside_a_generator_picks_other_kernels_not_other_values(gpu_model):
+    """vits_model_set_front_end_overlapped (what infer_batches sets for its front ends): at 16 x 3 s -- 4128 frames, beyond
+    the 2048 from which the frame-rate convs then leave the short-sequence kernel for the f16x2 one -- the reference
+    samples hold at the fp32 tolerance, durations and masks are the plain call's bytes, the waveform is within 1e-5 of
+    the plain call's and NOT its bytes (the other kernels did run); throughput mode returns exactly these bytes."""
+    from vits_amd import _native as N
+    b = synthetic.config_c2()
+    g = np.load(os.path.join(GOLDEN, "c2.npz"))
+    kw = dict(sid=b.sid, noise=b.noise, noise_scale=b.noise_scale, duration_control=b.durations)
+    plain = gpu_model.infer(b.phonemes, b.lengths, **kw)
+    N.check(N.lib.vits_model_set_front_end_overlapped(gpu_model._handle, 1))
+    try:
+        hinted = gpu_model.infer(b.phonemes, b.lengths, **kw)
+    finally:
+        N.check(N.lib.vits_model_set_front_end_overlapped(gpu_model._handle, 0))
+    assert np.abs(hinted[0][:, 0, ::97].cpu().numpy() - g["out_o_stride97"]).max() <= WAV_TOL
+    assert torch.equal(hinted[1], plain[1]) and torch.equal(hinted[3], plain[3])
+    assert metrics.max_abs(hinted[0], plain[0]) <= 1e-5 and not torch.equal(hinted[0], plain[0])
+    piped = next(iter(gpu_model.infer_batches([dict(phonemes=b.phonemes, phonemes_lengths=b.lengths, **kw)])))
+    assert torch.equal(piped[0], hinted[0])
+    assert not gpu_model.range_overflow()
+
+
 def test_infer_c4_corpus_slice(gpu_model, oracle_model):
     """BASELINE configs[3] (the 10 000-utterance corpus: lognormal lengths clipped to 88..1400 frames, sorted, cut
     into batches of <= 64): a fixed slice of its batches -- the longest, the shortest, the first ragged one and a
