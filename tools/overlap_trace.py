@@ -21,7 +21,7 @@ def main():
     net.to("cuda:0").load_state_dict(synthetic.synthetic_state_dict(cfg, include_enc_q=False))
     kws = []
     for i in range(n):
-        b = synthetic.make_batch(100 + i, [50] * B, [frames] * B)
+        b = synthetic.make_batch(100 + i, [max(50, frames * 50 // 258)] * B, [frames] * B)
         kws.append({k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in dict(
             phonemes=b.phonemes, phonemes_lengths=b.lengths, sid=b.sid, noise_scale=b.noise_scale,
             duration_control=b.durations, noise=b.noise).items()})

@@ -2750,6 +2750,16 @@ hipError_t launch_conv(const ConvDesc& d, ConvArgs a, hipStream_t stream) {
       if (alt_small) return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, p, stream);
       if (M % 64 == 0) {
         if (L <= 96 && M % 128 == 0) return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, p, stream);
+        // bf16x3 convs the split-K kernel declined (phoneme rate in a large batch: 64 x 160): the same 128 x 64 tiles
+        // while their grid fits the block slots -- half the chain, and a row of 160 steps wastes a sixth of its tiles
+        // instead of three eighths of one 256-step tile
+        static const bool b3_tile64 = [] {
+          const char* e = getenv("VITS_B3_TILE64");
+          return !(e && e[0] == '0');
+        }();
+        if (b3_tile64 && p == PREC_BF16X3 && !a.split_row && L <= 512 &&
+            (long long)((L + 63) / 64) * ((M + 127) / 128) * a.B <= 2LL * device_cu_count())
+          return launch_cfg<2, 1, 2, 2, MODE_PLAIN>(a, p, stream);
         // a grid that leaves most CUs empty (batch 1): 128 x 64 tiles, twice the blocks, half the chain
         if (p == PREC_F16X2 && M % 128 == 0 && small128_limit() > 0 &&
             (long long)((L + 63) / 64) * (M / 128) * a.B * 4 <= (long long)small128_limit() * device_cu_count())
