@@ -146,6 +146,11 @@ int vits_variance_adaptor(const vits_model* m, float* x, const int* lengths, con
  * frame counts totals [B] (dur_dtype: 0 f32, 1 i64, 2 i32, 3 f64).  The caller reads totals to size x_frame, then
  * gather writes x_frame [B, C, T] (zero beyond each row's frame count). */
 int vits_length_regulate_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, void* stream);
+/* The same, and report [B + 2] receives the frame counts again followed by the device words flag0 and flag1 point to
+ * (0 for NULL) as they stand when the plan runs: the caller's one device-to-host copy then covers the frame counts and
+ * its two status words (id-range errors of the embedding stages, the fp16-range flag) without a gather of its own. */
+int vits_length_regulate_plan_report(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, int* report,
+                                     const int* flag0, const int* flag1, void* stream);
 int vits_length_regulate(const float* x, const int* cum, const int* totals, int B, int C, int P, int T, float* x_frame,
                          void* stream);
 

@@ -69,6 +69,7 @@ def _load():
         "vits_variance_adaptor": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, i32, f32, vp, vp, i32, f32, vp, vp,
                                         vp, i64, vp]),
         "vits_length_regulate_plan": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+        "vits_length_regulate_plan_report": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
         "vits_length_regulate": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
         "vits_frame_prior": (i32, [vp, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp, i64, vp]),
         "vits_flow_workspace_bytes": (i64, [vp, i32, i32]),

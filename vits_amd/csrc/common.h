@@ -268,7 +268,8 @@ bool conv_takes_glb(const ConvDesc& d, int B, int L);
 hipError_t launch_stage_f16x2(const float* x, float* out, int B, int C, int L, float scale, float slope, int* range_flag,
                               hipStream_t s);
 // length regulator
-hipError_t launch_lr_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, hipStream_t s);
+hipError_t launch_lr_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, hipStream_t s,
+                          int* report = nullptr, const int* flag0 = nullptr, const int* flag1 = nullptr);
 hipError_t launch_lr_gather(const float* x, const int* cum, const int* totals, float* out, int B, int C, int P, int T,
                             hipStream_t s);
 

@@ -1102,8 +1102,11 @@ __device__ inline int dur_to_int(const void* dur, int dtype, long long i) {
   return (int)v;
 }
 
+// report (optional): [gridDim.x + 2] = the frame counts again, then the words flag0 and flag1 point to (0 for a null
+// pointer) -- everything the host reads after the plan, in one place, so that it takes one copy and no gather kernel
 __global__ __launch_bounds__(256) void lr_plan_kernel(const void* __restrict__ dur, int dtype, int P,
-                                                       int* __restrict__ cum, int* __restrict__ totals) {
+                                                       int* __restrict__ cum, int* __restrict__ totals,
+                                                       int* __restrict__ report, const int* flag0, const int* flag1) {
   __shared__ int buf[2][LR_MAX_P];
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int p = tid; p < P; p += 256) buf[0][p] = dur_to_int(dur, dtype, (long long)b * P + p);
@@ -1115,12 +1118,22 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(const void* __restrict__ d
     cur ^= 1;
   }
   for (int p = tid; p < P; p += 256) cum[(long long)b * P + p] = buf[cur][p];
-  if (tid == 0) totals[b] = buf[cur][P - 1];
+  if (tid == 0) {
+    totals[b] = buf[cur][P - 1];
+    if (report) {
+      report[b] = buf[cur][P - 1];
+      if (b == 0) {
+        report[gridDim.x] = flag0 ? *flag0 : 0;
+        report[gridDim.x + 1] = flag1 ? *flag1 : 0;
+      }
+    }
+  }
 }
 
-hipError_t launch_lr_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, hipStream_t s) {
+hipError_t launch_lr_plan(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, hipStream_t s, int* report,
+                          const int* flag0, const int* flag1) {
   if (B <= 0 || P <= 0 || P > LR_MAX_P || dur_dtype < 0 || dur_dtype > 3) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(lr_plan_kernel, dim3(B), dim3(256), 0, s, dur, dur_dtype, P, cum, totals);
+  hipLaunchKernelGGL(lr_plan_kernel, dim3(B), dim3(256), 0, s, dur, dur_dtype, P, cum, totals, report, flag0, flag1);
   return hipGetLastError();
 }
 

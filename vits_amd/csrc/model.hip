@@ -822,6 +822,14 @@ int vits_length_regulate_plan(const void* dur, int dur_dtype, int B, int P, int*
   return VITS_OK;
 }
 
+int vits_length_regulate_plan_report(const void* dur, int dur_dtype, int B, int P, int* cum, int* totals, int* report,
+                                     const int* flag0, const int* flag1, void* stream) {
+  if (!dur || !cum || !totals || !report) return fail(VITS_ERR_INVALID, "length_regulate_plan_report: null argument");
+  if (P > 2048) return fail(VITS_ERR_INVALID, "length regulator supports at most 2048 phonemes per utterance");
+  HIP_TRY(launch_lr_plan(dur, dur_dtype, B, P, cum, totals, (hipStream_t)stream, report, flag0, flag1));
+  return VITS_OK;
+}
+
 int vits_length_regulate(const float* x, const int* cum, const int* totals, int B, int C, int P, int T, float* x_frame,
                          void* stream) {
   if (!x || !cum || !totals || !x_frame) return fail(VITS_ERR_INVALID, "length_regulate: null argument");

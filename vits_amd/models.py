@@ -214,7 +214,10 @@ class SynthesizerTrn:
                 self._device_tensors.append(dw)
                 N.check(N.lib.vits_model_set_conv_alt(h, name.encode(), dw.data_ptr()), f"set_conv_alt {name}")
             N.check(N.lib.vits_model_finalize(h), "vits_model_finalize")
-            self._range = torch.zeros(1, dtype=torch.int32, device=self.device)
+            # two device status words that live as long as the model: [0] id-range errors of the embedding stages of
+            # the call in progress (zero unless one was just raised), [1] the sticky fp16-range flag
+            self._flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+            self._err, self._range = self._flags[0:1], self._flags[1:2]
             N.check(N.lib.vits_model_set_range_flag(h, self._range.data_ptr()), "set_range_flag")
             torch.cuda.synchronize(self.device)
         self._last_use = None
@@ -570,7 +573,10 @@ class SynthesizerTrn:
             lens = phonemes_lengths.to(dev, torch.int32).contiguous()
             if lens.numel() != B:
                 raise ValueError("phonemes_lengths must have one entry per batch row")
-            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            err = self._err                     # zero on entry: reset whenever it is reported, or was never read
+            if getattr(self, "_err_pending", False):
+                err.zero_()                     # the previous call ended before it read the word back
+            self._err_pending = True
             if speakers:
                 sids = sid.to(dev, torch.int64).contiguous().reshape(-1)
                 if sids.numel() != B:
@@ -628,11 +634,16 @@ class SynthesizerTrn:
                 d = dur_pred
             cum = torch.empty(B, P, dtype=torch.int32, device=dev)
             totals = torch.empty(B, dtype=torch.int32, device=dev)
-            N.check(lib.vits_length_regulate_plan(d.data_ptr(), _DUR_DTYPES[d.dtype], B, P, cum.data_ptr(),
-                                                  totals.data_ptr(), stream), "length_regulate_plan")
+            report = torch.empty(B + 2, dtype=torch.int32, device=dev)
+            N.check(lib.vits_length_regulate_plan_report(d.data_ptr(), _DUR_DTYPES[d.dtype], B, P, cum.data_ptr(),
+                                                         totals.data_ptr(), report.data_ptr(), err.data_ptr(),
+                                                         self._range.data_ptr(), stream), "length_regulate_plan")
             # one device-to-host copy: frame counts, id-range errors, and the fp16-range flag that generator calls
-            # before this one may have raised (synchronises the stream)
-            host = self._read_back(torch.cat([totals, err, self._range]))
+            # before this one may have raised (synchronises the stream); the plan kernel has put the three side by side
+            host = self._read_back(report)
+            self._err_pending = False
+            if int(host[-2]):
+                err.zero_()
             if int(host[-2]) & 1:
                 raise IndexError("phoneme id out of range of the symbol table")
             if int(host[-2]) & 2:
