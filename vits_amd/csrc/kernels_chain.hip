@@ -430,7 +430,7 @@ bool chain_profitable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
   if (!chain_fusable(c1, c2, npair)) return false;
   const int C = c1[0].M, K = c1[0].K;
   return c1[0].prec == PREC_BF16 ? listed("VITS_CHAIN_BF16", "32x3,64x3,32x7,64x7,32x11", C, K)
-                                 : listed("VITS_CHAIN_F16X2", "32x3,64x3", C, K);
+                                 : listed("VITS_CHAIN_F16X2", "32x3,64x3,32x7", C, K);
 }
 
 namespace {
