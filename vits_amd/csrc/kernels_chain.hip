@@ -476,11 +476,21 @@ int env_int(const char* name, int dflt) {
 // many columns a side (60 of a 256-step tile) but its first two pairs lose as many as its third alone (30), and fused
 // they take 6.4 ms where two pair launches take 7.4 (64 x 10 s).  VITS_CHAIN_SPLIT=0 switches that off.
 int chain_plan(const ConvDesc* c1, const ConvDesc* c2, int npair, int* seg) {
+  static const bool split = env_int("VITS_CHAIN_SPLIT", 1) != 0;
+  // f16x2, 7 taps: the first two pairs in one launch and the third on its own lose 18 columns a side instead of 36
+  // (three products a tap make the recomputed columns three times as dear as in bf16).  At 16 x 3 s, 32 channels: 740 us
+  // against 753 whole and 783 pair by pair; 64 channels: 1140 against 1228 whole and 1188 as six LDS-DMA conv launches;
+  // at 64 x 10 s 9.3 / 10.0 / 10.0 ms and 15.2 / 16.8 / 16.1 ms.  VITS_CHAIN_SPLIT_F16X2: the list ("none": off).
+  if (split && npair == 3 && c1[0].prec == PREC_F16X2 && listed("VITS_CHAIN_SPLIT_F16X2", "32x7,64x7", c1[0].M, c1[0].K) &&
+      chain_fusable(c1, c2, 2) && chain_fusable(c1 + 2, c2 + 2, 1)) {
+    seg[0] = 2;
+    seg[1] = 1;
+    return 2;
+  }
   if (chain_profitable(c1, c2, npair)) {
     seg[0] = npair;
     return 1;
   }
-  static const bool split = env_int("VITS_CHAIN_SPLIT", 1) != 0;
   if (split && npair == 3 && c1[0].prec == PREC_BF16 && c1[0].M == 64 && c1[0].K == 11 && chain_fusable(c1, c2, 2) &&
       pair_fusable(c1[2], c2[2])) {
     seg[0] = 2;

@@ -1229,7 +1229,9 @@ int vits_generator(const vits_model* m, const float* z, const int* lengths, cons
           pa.out = dst; pa.out_bs = (long long)rb.c1[0].Cin * L; pa.out_cs = L;
           pa.B = B; pa.L = L; pa.accumulate = last && j > 0; pa.slope = 0.1f;
           pa.range_flag = g_range_flag;
-          if (seg[g] == 1) HIP_TRY(launch_resblock_pair(rb.c1[q0], rb.c2[q0], pa, sj));
+          // a segment of one pair: the pair kernel where it is the better one (32 channels; 64 in bf16), else the
+          // whole-ResBlock kernel on that one pair (64 channels in f16x2: 384 against 499 us at 16 x 3 s, 7 taps)
+          if (seg[g] == 1 && pair_profitable(rb.c1[q0], rb.c2[q0])) HIP_TRY(launch_resblock_pair(rb.c1[q0], rb.c2[q0], pa, sj));
           else HIP_TRY(launch_resblock_chain(rb.c1.data() + q0, rb.c2.data() + q0, seg[g], pa, sj));
           q0 += seg[g];
           yin = dst;
