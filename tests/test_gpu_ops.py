@@ -547,6 +547,54 @@ def test_resblock_chain_fused(N, prec, C, k, dils, L, B, acc):
     assert (out.cpu() - y).abs().max() < (1e-4 if prec == "f16x2" else 5e-2)
 
 
+@pytest.mark.parametrize("dils,L,B,acc", [((1, 3, 5), 1000, 2, True), ((1, 3, 5), 104, 1, False), ((1, 3, 5), 105, 2, True),
+                                           ((1,), 333, 1, False), ((1, 3), 37, 2, True)])
+def test_resblock_chain_128_channels_bf16(N, dils, L, B, acc):
+    """The whole-ResBlock kernel's 128-channel build (plain bf16, three taps: the generator's second stage in bf16
+    mode) against the same convs launched one by one (bf16 operands, fp32 accumulation chunk by chunk and tap by tap:
+    the same bytes), across tile borders (104 owned steps a tile with dilations 1, 3, 5) and with the accumulate form."""
+    from vits_amd import weights
+    import ctypes as Ct
+    p, C, k = PREC["bf16"], 128, 3
+    g = torch.Generator().manual_seed(L + len(dils))
+    n = len(dils)
+    ws = [(torch.randn(C, C, k, generator=g) / math.sqrt(C * k), torch.randn(C, C, k, generator=g) / math.sqrt(C * k))
+          for _ in range(n)]
+    bs = [(dev(torch.randn(C, generator=g) * 0.3), dev(torch.randn(C, generator=g) * 0.3)) for _ in range(n)]
+    pk = [(dev(weights.pack_rows(w1, p)), dev(weights.pack_rows(w2, p))) for w1, w2 in ws]
+    x = dev(torch.randn(B, C, L, generator=g))
+    init = dev(torch.randn(B, C, L, generator=g))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def conv(pkw, bias, src, dst, dilation, flags, res=None):
+        N.check(N.lib.vits_op_conv1d(pkw.data_ptr(), bias.data_ptr(), C, C, k, dilation, 0, p, src.data_ptr(), B, L, 0, 0, 0,
+                                     N.ptr(res), dst.data_ptr(), flags, 1.0, 0.1, stream), "op_conv1d")
+    cur = x
+    for q in range(n):
+        last = q + 1 == n
+        t = torch.empty_like(x)
+        conv(pk[q][0], bs[q][0], cur, t, dils[q], N.F_IN_LRELU)
+        dst = init.clone() if last else torch.empty_like(x)
+        conv(pk[q][1], bs[q][1], t, dst, 1, N.F_IN_LRELU | N.F_RES | (N.F_ACCUM if (acc and last) else 0), res=cur)
+        cur = dst
+    ref = cur
+    out = init.clone()
+    N.check(N.lib.vits_op_resblock_chain(_ptr_array([a for a, _ in pk]), _ptr_array([a for a, _ in bs]),
+                                         _ptr_array([b for _, b in pk]), _ptr_array([b for _, b in bs]), C, k,
+                                         (Ct.c_int * n)(*dils), n, p, x.data_ptr(), out.data_ptr(), B, L, 1 if acc else 0,
+                                         0.1, stream), "chain")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    y = x.cpu()
+    for q in range(n):
+        (w1, w2), (b1, b2) = ws[q], bs[q]
+        t = F.conv1d(rq(F.leaky_relu(y, 0.1), p), rq(w1, p), b1.cpu(), padding=(k - 1) // 2 * dils[q], dilation=dils[q])
+        y = F.conv1d(rq(F.leaky_relu(t, 0.1), p), rq(w2, p), b2.cpu(), padding=(k - 1) // 2) + y
+    if acc:
+        y = y + init.cpu()
+    assert (out.cpu() - y).abs().max() < 5e-2
+
+
 def test_resblock_chain_refuses_unsupported_shapes(N):
     """Five pairs, halos that add up to more than 64 steps a side, in-place use and other channel or tap counts are
     errors, never launches."""

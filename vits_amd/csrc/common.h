@@ -190,6 +190,7 @@ struct PairArgs {
   int xcd_map = 0;               // launch_resblock_pair: blockIdx.x -> time tile goes through xcd_tile()
 };
 bool xcd_map_enabled();          // VITS_XCD_MAP=0 switches the mapping off (A/B measurements)
+bool pair_shape_fusable(const ConvDesc& c1, const ConvDesc& c2); // ... everything but the channel count
 bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2);       // the kernel supports the shape (32 or 64 channels)
 bool pair_profitable(const ConvDesc& c1, const ConvDesc& c2);    // ... and is the faster choice for it
 hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const PairArgs& a, hipStream_t stream);

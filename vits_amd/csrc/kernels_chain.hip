@@ -420,7 +420,9 @@ static int chain_radius(const ConvDesc* c1, int npair) {
 bool chain_fusable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
   if (npair < 1 || npair > CHAIN_MAX_PAIRS) return false;
   for (int p = 0; p < npair; ++p) {
-    if (!pair_fusable(c1[p], c2[p])) return false;
+    // 32 or 64 channels; 128 in plain bf16 with three taps (one build: 2 x 2 waves of 64 rows x 64 steps)
+    const bool channels = c1[p].M == 32 || c1[p].M == 64 || (c1[p].M == 128 && c1[p].prec == PREC_BF16 && c1[p].K == 3);
+    if (!pair_shape_fusable(c1[p], c2[p]) || !channels) return false;
     if (c1[p].M != c1[0].M || c1[p].K != c1[0].K || c1[p].prec != c1[0].prec) return false;
   }
   return chain_radius(c1, npair) <= 64;                     // a 256-step tile keeps at least half of its columns
@@ -429,7 +431,7 @@ bool chain_fusable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
 bool chain_profitable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
   if (!chain_fusable(c1, c2, npair)) return false;
   const int C = c1[0].M, K = c1[0].K;
-  return c1[0].prec == PREC_BF16 ? listed("VITS_CHAIN_BF16", "32x3,64x3,32x7,64x7,32x11", C, K)
+  return c1[0].prec == PREC_BF16 ? listed("VITS_CHAIN_BF16", "32x3,64x3,32x7,64x7,32x11,128x3", C, K)
                                  : listed("VITS_CHAIN_F16X2", "32x3,64x3,32x7", C, K);
 }
 
@@ -533,6 +535,7 @@ hipError_t launch_resblock_chain(const ConvDesc* c1, const ConvDesc* c2, int npa
   //                0: 128 steps, three blocks (k = 3: 722 against 651 us)
   static const int wide_from = env_int("VITS_CHAIN_WIDE_R", 0);
   static const int build32 = env_int("VITS_CHAIN_BUILD_32", -1), build64 = env_int("VITS_CHAIN_BUILD_64", 1);
+  if (MT == 4) return launch_build<4, 3, 1, 2, 2, 2, 4>(a, name, ta, stream);       // chain_fusable: bf16, three taps
   if (MT == 1) {
     int build = build32 >= 0 ? build32 : (NP == 1 && a.R >= wide_from) ? 1 : 0;
     if (build == 2 && 128 - 2 * a.R < 64) build = NP == 1 ? 1 : 0;       // a 128-step tile would keep too little

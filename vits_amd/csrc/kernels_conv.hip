@@ -3139,11 +3139,15 @@ bool pair_profitable(const ConvDesc& c1, const ConvDesc& c2) {
   return pair_fusable(c1, c2) && (c1.M == 32 || pair64_taps(c1.K));
 }
 
+// everything a fused pair needs but the channel count (which differs between the pair and the whole-ResBlock kernel)
+bool pair_shape_fusable(const ConvDesc& c1, const ConvDesc& c2) {
+  return (c1.prec == PREC_F16X2 || c1.prec == PREC_BF16) && c2.prec == c1.prec && c1.mode == MODE_PLAIN && c2.mode == MODE_PLAIN &&
+         c1.M == c1.Cin && c2.M == c1.M && c2.Cin == c1.M && c1.K == c2.K && (c1.K & 1) && c2.tstep[0] == 1 &&
+         (c1.K - 1) / 2 * c1.tstep[0] <= 25 && (c2.K - 1) / 2 <= PAIR_YOFF && c1.K >= 3 && c1.K <= 11;
+}
+
 bool pair_fusable(const ConvDesc& c1, const ConvDesc& c2) {
-  const bool shape = (c1.prec == PREC_F16X2 || c1.prec == PREC_BF16) && c2.prec == c1.prec && c1.mode == MODE_PLAIN && c2.mode == MODE_PLAIN &&
-                     c1.M == c1.Cin && c2.M == c1.M && c2.Cin == c1.M && c1.K == c2.K && (c1.K & 1) && c2.tstep[0] == 1 &&
-                     (c1.K - 1) / 2 * c1.tstep[0] <= 25 && (c2.K - 1) / 2 <= PAIR_YOFF;
-  return shape && (c1.M == 32 || c1.M == 64) && c1.K >= 3 && c1.K <= 11;
+  return pair_shape_fusable(c1, c2) && (c1.M == 32 || c1.M == 64);
 }
 
 hipError_t launch_resblock_pair(const ConvDesc& c1, const ConvDesc& c2, const PairArgs& a, hipStream_t stream) {
