@@ -248,7 +248,7 @@ int vits_op_resblock_pair_prec(const void* packed_w1, const float* bias1, const 
  * npair (1..4) dilations x = x + conv2(lrelu(conv1(lrelu(x)))), then out = x (+ out when accumulate: the sum of a
  * stage's ResBlocks, models.py:292-298).  packed_w1 / bias1 / packed_w2 / bias2: host arrays of npair device pointers
  * (weights packed for `precision`, 3 = f16x2 or 2 = bf16; a bias array or an entry of it may be NULL); C = 32 or 64,
- * or 128 with precision 2 and 3 taps;
+ * or 128 with 3 taps (the same bytes as the convs called one by one there: the pair ops stop at 64 channels);
  * the same tap count for every conv; the halos of the pairs, (taps - 1) / 2 * (dilation + 1) each, add up to at most
  * 64 steps.  Same bytes as npair calls of vits_op_resblock_pair(_prec).  x and out [B, C, L], not overlapping. */
 int vits_op_resblock_chain(const void* const* packed_w1, const float* const* bias1, const void* const* packed_w2,

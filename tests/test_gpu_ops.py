@@ -547,15 +547,16 @@ def test_resblock_chain_fused(N, prec, C, k, dils, L, B, acc):
     assert (out.cpu() - y).abs().max() < (1e-4 if prec == "f16x2" else 5e-2)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16x2"])
 @pytest.mark.parametrize("dils,L,B,acc", [((1, 3, 5), 1000, 2, True), ((1, 3, 5), 104, 1, False), ((1, 3, 5), 105, 2, True),
                                            ((1,), 333, 1, False), ((1, 3), 37, 2, True)])
-def test_resblock_chain_128_channels_bf16(N, dils, L, B, acc):
-    """The whole-ResBlock kernel's 128-channel build (plain bf16, three taps: the generator's second stage in bf16
-    mode) against the same convs launched one by one (bf16 operands, fp32 accumulation chunk by chunk and tap by tap:
-    the same bytes), across tile borders (104 owned steps a tile with dilations 1, 3, 5) and with the accumulate form."""
+def test_resblock_chain_128_channels(N, prec, dils, L, B, acc):
+    """The whole-ResBlock kernel's 128-channel builds (three taps: the generator's second stage) against the same convs
+    launched one by one (the same operands, fp32 accumulation chunk by chunk and tap by tap: the same bytes), across
+    tile borders (104 owned steps a tile with dilations 1, 3, 5) and with the accumulate form."""
     from vits_amd import weights
     import ctypes as Ct
-    p, C, k = PREC["bf16"], 128, 3
+    p, C, k = PREC[prec], 128, 3
     g = torch.Generator().manual_seed(L + len(dils))
     n = len(dils)
     ws = [(torch.randn(C, C, k, generator=g) / math.sqrt(C * k), torch.randn(C, C, k, generator=g) / math.sqrt(C * k))
@@ -592,7 +593,7 @@ def test_resblock_chain_128_channels_bf16(N, dils, L, B, acc):
         y = F.conv1d(rq(F.leaky_relu(t, 0.1), p), rq(w2, p), b2.cpu(), padding=(k - 1) // 2) + y
     if acc:
         y = y + init.cpu()
-    assert (out.cpu() - y).abs().max() < 5e-2
+    assert (out.cpu() - y).abs().max() < (1e-4 if prec == "f16x2" else 5e-2)
 
 
 def test_resblock_chain_refuses_unsupported_shapes(N):

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
 #ifndef CHAIN_RING3
 #define CHAIN_RING3 4
 #endif
-  constexpr int D = chain_ring(2 * NT, BPC >= 3 ? (NP == 2 ? CHAIN_RING3 : 4) : WR == 2 ? 4 : (NJ == 4 && NP == 2) ? 3 : 8);
+  constexpr int D = chain_ring(2 * NT, BPC >= 3 ? (NP == 2 ? CHAIN_RING3 : 4) : (MT == 4 && NP == 2) ? 2 : WR == 2 ? 4 : (NJ == 4 && NP == 2) ? 3 : 8);
   static_assert((2 * NT) % D == 0 && D >= 2, "ring slots must line up across pairs");
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -243,6 +243,9 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
         if constexpr (!(CHAIN_KO & 2)) fetch_a(g + D);
 #ifdef CHAIN_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
+#else
+        // the 128-channel f16x2 build has no register to spare for fragments of later taps read ahead of time
+        if constexpr (MT == 4 && NP == 2) __builtin_amdgcn_sched_barrier(0);
 #endif
       }
   };
@@ -293,6 +296,8 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
       if constexpr (NP == 2) t2[(((chunk * NP + 1) * 2 + half) * COLS + col) * 2 + par] = ol;
 #ifdef CHAIN_SCHED_BARRIER2
       __builtin_amdgcn_sched_barrier(0);       // four values at a time: the conversion's temporaries stay few
+#else
+      if constexpr (MT == 4 && NP == 2) __builtin_amdgcn_sched_barrier(0);
 #endif
     }
   };
@@ -421,7 +426,7 @@ bool chain_fusable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
   if (npair < 1 || npair > CHAIN_MAX_PAIRS) return false;
   for (int p = 0; p < npair; ++p) {
     // 32 or 64 channels; 128 in plain bf16 with three taps (one build: 2 x 2 waves of 64 rows x 64 steps)
-    const bool channels = c1[p].M == 32 || c1[p].M == 64 || (c1[p].M == 128 && c1[p].prec == PREC_BF16 && c1[p].K == 3);
+    const bool channels = c1[p].M == 32 || c1[p].M == 64 || (c1[p].M == 128 && c1[p].K == 3);
     if (!pair_shape_fusable(c1[p], c2[p]) || !channels) return false;
     if (c1[p].M != c1[0].M || c1[p].K != c1[0].K || c1[p].prec != c1[0].prec) return false;
   }
@@ -432,7 +437,7 @@ bool chain_profitable(const ConvDesc* c1, const ConvDesc* c2, int npair) {
   if (!chain_fusable(c1, c2, npair)) return false;
   const int C = c1[0].M, K = c1[0].K;
   return c1[0].prec == PREC_BF16 ? listed("VITS_CHAIN_BF16", "32x3,64x3,32x7,64x7,32x11,128x3", C, K)
-                                 : listed("VITS_CHAIN_F16X2", "32x3,64x3,32x7", C, K);
+                                 : listed("VITS_CHAIN_F16X2", "32x3,64x3,32x7,128x3", C, K);
 }
 
 namespace {
@@ -535,7 +540,11 @@ hipError_t launch_resblock_chain(const ConvDesc* c1, const ConvDesc* c2, int npa
   //                0: 128 steps, three blocks (k = 3: 722 against 651 us)
   static const int wide_from = env_int("VITS_CHAIN_WIDE_R", 0);
   static const int build32 = env_int("VITS_CHAIN_BUILD_32", -1), build64 = env_int("VITS_CHAIN_BUILD_64", 1);
-  if (MT == 4) return launch_build<4, 3, 1, 2, 2, 2, 4>(a, name, ta, stream);       // chain_fusable: bf16, three taps
+  if (MT == 4)                                                                   // chain_fusable: three taps
+  {
+    if (NP == 1) return launch_build<4, 3, 1, 2, 2, 2, 4>(a, name, ta, stream);
+    return launch_build<4, 3, 2, 2, 2, 2, 4>(a, name, ta, stream);
+  }
   if (MT == 1) {
     int build = build32 >= 0 ? build32 : (NP == 1 && a.R >= wide_from) ? 1 : 0;
     if (build == 2 && 128 - 2 * a.R < 64) build = NP == 1 ? 1 : 0;       // a 128-step tile would keep too little

@@ -1380,7 +1380,7 @@ int vits_op_resblock_chain(const void* const* w1, const float* const* b1, const 
     TRY(make_desc(c2[p], w2[p], b2 ? b2[p] : nullptr, channels, channels, taps, 1, MODE_PLAIN, precision));
   }
   if (!chain_fusable(c1, c2, npair))
-    return fail(VITS_ERR_INVALID, "resblock chain: 1 to 4 pairs of 32 or 64 channels (128 in bf16 with 3 taps) and 3 / 5 / 7 / 9 / 11 taps whose "
+    return fail(VITS_ERR_INVALID, "resblock chain: 1 to 4 pairs of 32 or 64 channels (128 with 3 taps) and 3 / 5 / 7 / 9 / 11 taps whose "
                                   "halos add up to at most 64 steps a side required");
   if (x == out) return fail(VITS_ERR_INVALID, "resblock chain: cannot run in place");
   PairArgs pa;
