@@ -30,6 +30,15 @@ _DUR_DTYPES = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.float64: 
 _SPIN_US = float(os.environ.get("VITS_READBACK_SPIN_US", "2000"))
 
 
+def _rccl_group_live() -> bool:
+    """True when this process already holds a torch.distributed group on the nccl (= RCCL) backend."""
+    try:
+        import torch.distributed as dist
+        return bool(dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend()))
+    except Exception:           # no distributed support in this torch build: no communicator either
+        return False
+
+
 class SynthesizerTrn:
     """Inference-only synthesizer: infer, infer_stream and voice_conversion (the posterior encoder is built when the
     checkpoint holds its weights; the reference's training forward and discriminators are not)."""
@@ -38,6 +47,7 @@ class SynthesizerTrn:
     # every model: the device schedules four hardware queues at once, and a pair per model would put a second model's
     # pipeline onto queues the first one's streams already hold (measured: 6.7 % slower).
     _PIPELINE: Dict[int, tuple] = {}
+    _COMM_FIRST: Dict[int, bool] = {}
 
     def __init__(self, n_vocab, spec_channels, hop_length, sampling_rate, segment_size, inter_channels,
                  hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, resblock,
@@ -366,6 +376,8 @@ class SynthesizerTrn:
                     # slots the generator's blocks free up instead of queueing behind whole generator launches
                     prio = int(os.environ.get("VITS_FE_PRIORITY", "-1"))
                     SynthesizerTrn._PIPELINE[dev.index] = (torch.cuda.Stream(dev, priority=prio), torch.cuda.Stream(dev))
+                    # a communicator set up before these streams already holds hardware queues of its own
+                    SynthesizerTrn._COMM_FIRST[dev.index] = _rccl_group_live()
                 if getattr(self, "_s_fe", None) is None or self._s_fe.device != dev:
                     self._s_fe, self._s_gen = SynthesizerTrn._PIPELINE[dev.index]
                     self._ws_gen = None
@@ -376,7 +388,11 @@ class SynthesizerTrn:
                 # share four, a high-priority stream has one of its own), and four are what the device schedules at
                 # once.  Called on the default stream that is default + front end + generator + one side stream; a
                 # caller on a stream of its own already holds the fourth, so the generator then stays on one stream.
-                gen_streams = 2 if caller == torch.cuda.default_stream(dev) else 1
+                # An RCCL process group that was initialised before this model's streams existed took its queues first,
+                # and the generator's side stream would then share one with another stream of this call (a C2 step
+                # measured 15.1 ms instead of 11.5; 12.0 with the chains on one stream): set the model up and run one
+                # infer_batches before init_process_group, and none of this applies.
+                gen_streams = 2 if caller == torch.cuda.default_stream(dev) and not SynthesizerTrn._COMM_FIRST.get(dev.index) else 1
                 N.check(lib.vits_model_set_generator_streams(h, int(os.environ.get("VITS_BATCHES_GEN_STREAMS", gen_streams))),
                         "set_generator_streams")
                 # every front end of this call runs beside a generator (all but the first, and the first takes the same
