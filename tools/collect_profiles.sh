@@ -6,7 +6,7 @@ R=${1:-r03}
 P="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-sub-results --serial-generator --no-overlap"
 C3="bench.py --batch 64 --frames 861 --phonemes 160 --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-sub-results --serial-generator --no-overlap"
 python3 tools/summarize_rocprof.py gpurun_out/refresh/kt profiles/${R}_f16x2_kernel_stats.md \
-  "$P (f16x2 default; LDS-DMA convs for the 64/128/256-channel ResBlock layers, whole-ResBlock kernel for the 3-tap ResBlocks at 32 and 64 channels, fused pairs for the 7- and 11-tap ones at 32)"
+  "$P (f16x2 default; LDS-DMA convs for the 64/128/256-channel ResBlock layers, whole-ResBlock kernel for the 3-tap ResBlocks at 32, 64 and 128 channels and for the 7-tap ones (first two pairs) at 32 and 64, fused pairs for the 11-tap ones at 32)"
 cp gpurun_out/refresh/kt_bench.json profiles/${R}_f16x2_bench_under_rocprof.json
 python3 tools/pmc_traffic_json.py gpurun_out/refresh/pmc profiles/${R}_pmc_traffic.json "python3 $P" > /dev/null
 python3 tools/summarize_rocprof.py gpurun_out/refresh/b1 profiles/${R}_c1_batch1_kernel_stats.md \
