@@ -88,7 +88,10 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
 #ifndef CHAIN_RING3
 #define CHAIN_RING3 4
 #endif
-  constexpr int D = chain_ring(2 * NT, BPC >= 3 ? (NP == 2 ? CHAIN_RING3 : 4) : (MT == 4 && NP == 2) ? 2 : WR == 2 ? 4 : (NJ == 4 && NP == 2) ? 3 : 8);
+#ifndef CHAIN_RING128
+#define CHAIN_RING128 2
+#endif
+  constexpr int D = chain_ring(2 * NT, BPC >= 3 ? (NP == 2 ? CHAIN_RING3 : 4) : (MT == 4 && NP == 2) ? CHAIN_RING128 : WR == 2 ? 4 : (NJ == 4 && NP == 2) ? 3 : 8);
   static_assert((2 * NT) % D == 0 && D >= 2, "ring slots must line up across pairs");
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -251,7 +254,6 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
   };
   // One accumulator tile (row tile i of the wave, n-tile j) -> leaky-relu, (clamp, split into fp16 h / l | round to
   // bf16), zero outside the sequence -> operand tile
-  uint2* t2 = reinterpret_cast<uint2*>(lds);
   // A conv's operand is zero outside the sequence (its zero padding): 1 or 0 per column, multiplied in before the
   // leaky-relu (exact for the columns that stay; two packed multiplies and a max per pair of values in all)
   float inside[NJ];
@@ -261,15 +263,15 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
     const f32x2 keep = {inside[j], inside[j]}, slope2 = {a.slope, a.slope};
     const int col = a.H + c0 + 32 * j;
     const int rt = wm * WR + i;
+    uint2 oh[4], ol[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      uint2 oh, ol;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         f32x2 e = {v(4 * g + 2 * u), v(4 * g + 2 * u + 1)};
         if constexpr (CHAIN_KO & 4) {
-          (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, e[0]);
-          (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, e[1]);
+          (u ? oh[g].y : oh[g].x) = __builtin_bit_cast(unsigned, e[0]);
+          (u ? ol[g].y : ol[g].x) = __builtin_bit_cast(unsigned, e[1]);
         } else {
           e = e * keep;
           const f32x2 es = e * slope2;
@@ -285,20 +287,35 @@ __global__ __launch_bounds__(64 * NW, BPC) void resblock_chain_kernel(const Chai
         } else if constexpr (NP == 2) {
           const f16x2 h = __builtin_convertvector(e, f16x2);
           const f16x2 l = __builtin_convertvector(e - __builtin_convertvector(h, f32x2), f16x2);
-          (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, h);
-          (u ? ol.y : ol.x) = __builtin_bit_cast(unsigned, l);
+          (u ? oh[g].y : oh[g].x) = __builtin_bit_cast(unsigned, h);
+          (u ? ol[g].y : ol[g].x) = __builtin_bit_cast(unsigned, l);
         } else {
-          (u ? oh.y : oh.x) = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2));
+          (u ? oh[g].y : oh[g].x) = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2));
         }
       }
-      const int chunk = 2 * rt + (g >> 1), half = g & 1;
-      t2[(((chunk * NP + 0) * 2 + half) * COLS + col) * 2 + par] = oh;
-      if constexpr (NP == 2) t2[(((chunk * NP + 1) * 2 + half) * COLS + col) * 2 + par] = ol;
+      if (g & 1) {
+        // A 16-byte unit (eight channels of a column) is four channels of lane l and four of lane l + 32.  The two
+        // lanes trade one half each -- l gives its part of the odd unit for l + 32's part of the even one -- and
+        // write whole units: l the even one, l + 32 the odd one, 512 contiguous bytes per half wave.
+        // (the wait states stand in for the hazard checks the compiler does not make inside an asm statement)
+        if constexpr (NP == 2)
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                       "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\ts_nop 1"
+                       : "+v"(oh[g - 1].x), "+v"(oh[g].x), "+v"(oh[g - 1].y), "+v"(oh[g].y),
+                         "+v"(ol[g - 1].x), "+v"(ol[g].x), "+v"(ol[g - 1].y), "+v"(ol[g].y));
+        else
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                       : "+v"(oh[g - 1].x), "+v"(oh[g].x), "+v"(oh[g - 1].y), "+v"(oh[g].y));
+        const int chunk = 2 * rt + (g >> 1);
+        lds[((chunk * NP + 0) * 2 + par) * COLS + col] = make_uint4(oh[g - 1].x, oh[g - 1].y, oh[g].x, oh[g].y);
+        if constexpr (NP == 2)
+          lds[((chunk * NP + 1) * 2 + par) * COLS + col] = make_uint4(ol[g - 1].x, ol[g - 1].y, ol[g].x, ol[g].y);
 #ifdef CHAIN_SCHED_BARRIER2
-      __builtin_amdgcn_sched_barrier(0);       // four values at a time: the conversion's temporaries stay few
+        __builtin_amdgcn_sched_barrier(0);       // eight values at a time: the conversion's temporaries stay few
 #else
-      if constexpr (MT == 4 && NP == 2) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MT == 4 && NP == 2) __builtin_amdgcn_sched_barrier(0);
 #endif
+      }
     }
   };
 
