@@ -329,3 +329,38 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
     with pytest.raises(SystemExit, match="needs a GPU per rank"):
         bench.main()
+
+
+def test_bench_sets_up_the_process_group_after_the_models_streams(monkeypatch):
+    """A rank of bench.py builds the model and puts work on its streams before it initialises the process group: a
+    communicator's streams that came first would take hardware queues the model's four streams need (the step was a
+    quarter slower that way).  And the model side notices a live RCCL group only when there is one."""
+    import importlib.util
+    import torch.distributed as dist
+    spec = importlib.util.spec_from_file_location("bench_order_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    order = []
+
+    class Stop(Exception):
+        pass
+
+    def init(*a, **k):
+        order.append("init_process_group")
+        raise Stop()
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(bench.torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(bench, "build_model", lambda device, precision=None: order.append("build_model") or object())
+    monkeypatch.setattr(bench, "claim_streams", lambda net, device: order.append("claim_streams"))
+    monkeypatch.setattr(dist, "init_process_group", init)
+    for k, v in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("VITS_BENCH_FORCE_DIST", "1")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("VITS_BENCH_DIST_EARLY", raising=False)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "1"])
+    with pytest.raises(Stop):
+        bench.main()
+    assert order == ["build_model", "claim_streams", "init_process_group"]
+
+    from vits_amd import models
+    assert models._rccl_group_live() is False
