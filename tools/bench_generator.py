@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generator-only timing on a fixed latent (C2 shape by default): the front end runs once, then vits_generator is
-called back to back with 1 / 2 / 3 chain streams.  usage  python tools/bench_generator.py [B] [frames] [iters]"""
+called back to back, and with a host wait after every call, with 1 / 2 / 3 chain streams.  usage  python tools/bench_generator.py [B] [frames] [iters]"""
 import os
 import sys
 import time
@@ -41,7 +41,15 @@ def main():
             gen()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / iters * 1e3
-        print(f"generator B={B} T={T} chain streams={streams}: {ms:.3f} ms per call", flush=True)
+        # the same with the host waiting for every call before it enqueues the next (what a pipeline that allows one
+        # generator call in flight pays between two calls)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            gen()
+            torch.cuda.synchronize()
+        ms_sync = (time.perf_counter() - t0) / iters * 1e3
+        print(f"generator B={B} T={T} chain streams={streams}: {ms:.3f} ms per call back to back, {ms_sync:.3f} ms with a "
+              f"host wait after each", flush=True)
 
 
 if __name__ == "__main__":
